@@ -1,0 +1,20 @@
+"""Compile libhnsw_amd.so (host index + HIP kernels for gfx950 + C ABI) in-tree."""
+from __future__ import annotations
+
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "libhnsw_amd.so")
+
+
+def build(verbose: bool = False) -> str:
+    out = None if verbose else subprocess.DEVNULL
+    subprocess.check_call(["make", "-C", os.path.join(HERE, "csrc"), "all"], stdout=out)
+    if not os.path.exists(LIB):
+        raise RuntimeError("libhnsw_amd.so was not produced")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(verbose=True))

@@ -1,0 +1,88 @@
+"""ctypes binding of the C ABI in include/hnsw_amd.h (libhnsw_amd.so).
+
+The library is the product; it must exist (built in-tree by hnsw_amd.build).  There is
+no fallback: a missing library raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhnsw_amd.so")
+
+OK, E_ARG, E_FULL, E_IO, E_HIP, E_SCRATCH, E_GRAPH = 0, -1, -2, -3, -4, -5, -6
+DIST_SSE, DIST_SCALAR = 0, 1
+KEYS_INT32, KEYS_FLOAT = 0, 2
+
+_u32p = C.POINTER(C.c_uint32)
+_f32p = C.POINTER(C.c_float)
+_i32p = C.POINTER(C.c_int32)
+
+STATS_DTYPE = np.dtype([("n_dist", "<u4"), ("n_expand", "<u4"), ("n_sweeps", "<u4"), ("sum_deg0", "<u4"),
+                        ("sum_degu", "<u4"), ("max_c", "<u4"), ("n_visited0", "<u4"), ("n_visited_up", "<u4")])
+
+
+class FlatGraphC(C.Structure):
+    _fields_ = [("n", C.c_uint32), ("d", C.c_uint32), ("nlayers", C.c_uint32), ("deg0", C.c_uint32), ("degu", C.c_uint32),
+                ("adj0", _u32p), ("cnt0", _u32p), ("up_off", _u32p), ("up_order", _u32p), ("up_down", _u32p),
+                ("up_cnt", _u32p), ("up_adj_slot", _u32p), ("up_adj_order", _u32p), ("ep_slot", _u32p), ("ep_order", _u32p)]
+
+
+# every symbol include/hnsw_amd.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "hnsw_amd_last_error": (C.c_char_p, []),
+    "hnsw_amd_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "hnsw_amd_destroy": (None, [C.c_void_p]),
+    "hnsw_amd_init": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
+    "hnsw_amd_insert": (C.c_int, [C.c_void_p, _f32p]),
+    "hnsw_amd_insert_batch": (C.c_int, [C.c_void_p, _f32p, C.c_uint32, C.c_int]),
+    "hnsw_amd_aproximate_knn": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_uint32, _u32p, _f32p, _u32p]),
+    "hnsw_amd_search_batch": (C.c_int, [C.c_void_p, _f32p, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, _u32p, _f32p,
+                                        _u32p, C.c_void_p]),
+    "hnsw_amd_search_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32,
+                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _u32p]),
+    "hnsw_amd_save_graph": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "hnsw_amd_load_graph": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "hnsw_amd_import_flat": (C.c_int, [C.c_void_p, C.POINTER(FlatGraphC), _f32p]),
+    "hnsw_amd_export_flat": (C.c_int, [C.c_void_p, C.POINTER(FlatGraphC), C.POINTER(_f32p)]),
+    "hnsw_amd_sync_device": (C.c_int, [C.c_void_p, C.c_int]),
+    "hnsw_amd_get_info": (C.c_int, [C.c_void_p, _i32p, _i32p, _i32p, _i32p, _u32p, _i32p, _i32p, _u32p]),
+}
+
+_LIB = None
+
+
+class HnswAmdError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"hnsw_amd error {code}: {msg}")
+        self.code = code
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: build it with `python -m hnsw_amd.build` (there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)       # AttributeError if the library does not export it
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def check(rc: int) -> None:
+    if rc != OK:
+        raise HnswAmdError(rc, lib().hnsw_amd_last_error().decode(errors="replace"))
+
+
+def f32(a: np.ndarray):
+    return a.ctypes.data_as(_f32p)
+
+
+def u32(a: np.ndarray):
+    return a.ctypes.data_as(_u32p)

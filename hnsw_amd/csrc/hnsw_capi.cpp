@@ -1,0 +1,233 @@
+// extern "C" layer of libhnsw_amd.so: include/hnsw_amd.h implemented over HostIndex
+// (construction, files) and DeviceIndex (HBM copy + HIP search kernels).
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <ios>
+#include <new>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/hnsw_amd.h"
+#include "hnsw_device.h"
+#include "hnsw_host.h"
+
+using namespace hnsw_amd;
+
+struct hnsw_amd_index {
+    HostIndex host;
+    DeviceIndex dev;
+    int device = 0;
+    FlatGraph exported;
+    // grow-only device staging of the host-pointer search entry points
+    void* d_q = nullptr; size_t q_bytes = 0;
+    void* d_ids = nullptr; void* d_dist = nullptr; size_t out_elems = 0;
+    void* d_cnt = nullptr; void* d_stats = nullptr; size_t nq_cap = 0;
+    hnsw_amd_index(int M, int Mmax, int efC) : host(M, Mmax, efC) {}
+};
+
+static thread_local std::string g_err;
+
+template <class F>
+static int guarded(F&& f)
+{
+    try {
+        f();
+        return HNSW_AMD_OK;
+    } catch (const std::ios_base::failure& e) { g_err = e.what(); return HNSW_AMD_E_IO;
+    } catch (const std::domain_error& e) { g_err = e.what(); return HNSW_AMD_E_GRAPH;
+    } catch (const std::length_error& e) { g_err = e.what(); return HNSW_AMD_E_SCRATCH;
+    } catch (const std::invalid_argument& e) { g_err = e.what(); return HNSW_AMD_E_ARG;
+    } catch (const std::logic_error& e) { g_err = e.what(); return HNSW_AMD_E_ARG;
+    } catch (const std::runtime_error& e) {
+        g_err = e.what();
+        if (g_err.rfind("HIP:", 0) == 0) return HNSW_AMD_E_HIP;
+        if (g_err.rfind("HNSW: exceeded", 0) == 0) return HNSW_AMD_E_FULL;
+        return HNSW_AMD_E_ARG;
+    } catch (const std::bad_alloc&) { g_err = "out of host memory"; return HNSW_AMD_E_ARG;
+    } catch (...) { g_err = "unknown error"; return HNSW_AMD_E_ARG; }
+}
+
+#define REQUIRE(cond, msg) do { if (!(cond)) throw std::invalid_argument(msg); } while (0)
+#define HIP_OK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) throw std::runtime_error(std::string("HIP: ") + #expr + ": " + hipGetErrorString(e_)); } while (0)
+
+static void ensure_device_copy(hnsw_amd_index* h)
+{
+    if (h->dev.device != h->device || h->dev.version != h->host.version_) h->dev.upload(h->host, h->device);
+}
+
+extern "C" {
+
+const char* hnsw_amd_last_error(void) { return g_err.c_str(); }
+
+int hnsw_amd_create(int M, int Mmax, int efConstruction, hnsw_amd_index** out)
+{
+    return guarded([&] {
+        REQUIRE(out != nullptr, "create: out is NULL");
+        REQUIRE(M >= 2 && Mmax >= M && Mmax <= 32, "create: need 2 <= M <= Mmax <= 32");
+        REQUIRE(efConstruction >= 1, "create: efConstruction must be positive");
+        *out = new hnsw_amd_index(M, Mmax, efConstruction);
+    });
+}
+
+void hnsw_amd_destroy(hnsw_amd_index* h)
+{
+    if (!h) return;
+    if (h->dev.device >= 0) (void)hipSetDevice(h->dev.device);
+    for (void* p : {h->d_q, h->d_ids, h->d_dist, h->d_cnt, h->d_stats}) if (p) (void)hipFree(p);
+    delete h;
+}
+
+int hnsw_amd_init(hnsw_amd_index* h, uint32_t vector_size, uint32_t max_node_count)
+{
+    return guarded([&] {
+        REQUIRE(h, "init: index is NULL");
+        REQUIRE(vector_size >= 1 && vector_size <= 65536, "init: vector_size out of range");
+        REQUIRE(max_node_count >= 1 && max_node_count < 0x7FFFFFFFu, "init: max_node_count out of range");
+        h->host.init(vector_size, max_node_count);
+    });
+}
+
+int hnsw_amd_insert(hnsw_amd_index* h, const float* q)
+{
+    return guarded([&] { REQUIRE(h && q, "insert: NULL argument"); h->host.insert(q); });
+}
+
+int hnsw_amd_insert_batch(hnsw_amd_index* h, const float* rows, uint32_t n, int threads)
+{
+    return guarded([&] { REQUIRE(h && (rows || n == 0), "insert_batch: NULL argument"); h->host.insert_batch(rows, n, threads); });
+}
+
+int hnsw_amd_sync_device(hnsw_amd_index* h, int device)
+{
+    return guarded([&] {
+        REQUIRE(h, "sync_device: index is NULL");
+        int count = 0;
+        HIP_OK(hipGetDeviceCount(&count));
+        REQUIRE(device >= 0 && device < count, "sync_device: no such GPU");
+        h->device = device;
+        ensure_device_copy(h);
+    });
+}
+
+int hnsw_amd_search_batch_device(hnsw_amd_index* h, const float* d_queries, uint32_t nq, int ef, uint32_t out_k,
+                                 uint32_t flags, uint32_t* d_out_ids, float* d_out_dist, uint32_t* d_out_count,
+                                 hnsw_amd_query_stats* d_stats, void* stream, uint32_t* retried)
+{
+    return guarded([&] {
+        REQUIRE(h && d_queries && d_out_ids && d_out_dist, "search_batch_device: NULL argument");
+        ensure_device_copy(h);
+        uint32_t r = h->dev.search(d_queries, nq, ef, out_k, flags, d_out_ids, d_out_dist, d_out_count, d_stats, stream, true);
+        if (retried) *retried = r;
+    });
+}
+
+int hnsw_amd_search_batch(hnsw_amd_index* h, const float* queries, uint32_t nq, int ef, uint32_t out_k, uint32_t flags,
+                          uint32_t* out_ids, float* out_dist, uint32_t* out_count, hnsw_amd_query_stats* stats)
+{
+    return guarded([&] {
+        REQUIRE(h && (queries || nq == 0) && out_ids && out_dist, "search_batch: NULL argument");
+        if (nq == 0) return;
+        ensure_device_copy(h);
+        HIP_OK(hipSetDevice(h->device));
+        const size_t qb = (size_t)nq * h->host.vector_size_ * sizeof(float);
+        const size_t oe = (size_t)nq * out_k;
+        if (qb > h->q_bytes) { if (h->d_q) HIP_OK(hipFree(h->d_q)); h->d_q = nullptr; HIP_OK(hipMalloc(&h->d_q, qb)); h->q_bytes = qb; }
+        if (oe > h->out_elems) {
+            if (h->d_ids) HIP_OK(hipFree(h->d_ids));
+            if (h->d_dist) HIP_OK(hipFree(h->d_dist));
+            h->d_ids = h->d_dist = nullptr;
+            HIP_OK(hipMalloc(&h->d_ids, oe * 4)); HIP_OK(hipMalloc(&h->d_dist, oe * 4)); h->out_elems = oe;
+        }
+        if (nq > h->nq_cap) {
+            if (h->d_cnt) HIP_OK(hipFree(h->d_cnt));
+            if (h->d_stats) HIP_OK(hipFree(h->d_stats));
+            h->d_cnt = h->d_stats = nullptr;
+            HIP_OK(hipMalloc(&h->d_cnt, (size_t)nq * 4)); HIP_OK(hipMalloc(&h->d_stats, (size_t)nq * sizeof(hnsw_amd_query_stats)));
+            h->nq_cap = nq;
+        }
+        HIP_OK(hipMemcpy(h->d_q, queries, qb, hipMemcpyHostToDevice));
+        h->dev.search((const float*)h->d_q, nq, ef, out_k, flags, (uint32_t*)h->d_ids, (float*)h->d_dist, (uint32_t*)h->d_cnt,
+                      (hnsw_amd_query_stats*)h->d_stats, nullptr, true);
+        HIP_OK(hipMemcpy(out_ids, h->d_ids, oe * 4, hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(out_dist, h->d_dist, oe * 4, hipMemcpyDeviceToHost));
+        if (out_count) HIP_OK(hipMemcpy(out_count, h->d_cnt, (size_t)nq * 4, hipMemcpyDeviceToHost));
+        if (stats) HIP_OK(hipMemcpy(stats, h->d_stats, (size_t)nq * sizeof(hnsw_amd_query_stats), hipMemcpyDeviceToHost));
+    });
+}
+
+int hnsw_amd_aproximate_knn(hnsw_amd_index* h, const float* q, int k, int ef, uint32_t flags, uint32_t* out_ids,
+                            float* out_dist, uint32_t* out_count)
+{
+    (void)k;   // ignored by the reference as well (src/hnsw.cpp:373: W_ keeps up to ef entries)
+    return hnsw_amd_search_batch(h, q, 1, ef, (uint32_t)(ef > 0 ? ef : 1), flags, out_ids, out_dist, out_count, nullptr);
+}
+
+int hnsw_amd_save_graph(hnsw_amd_index* h, const char* filename)
+{
+    return guarded([&] { REQUIRE(h && filename, "save_graph: NULL argument"); h->host.save_graph(filename); });
+}
+
+int hnsw_amd_load_graph(hnsw_amd_index* h, const char* filename)
+{
+    return guarded([&] { REQUIRE(h && filename, "load_graph: NULL argument"); h->host.load_graph(filename); });
+}
+
+int hnsw_amd_import_flat(hnsw_amd_index* h, const hnsw_amd_flat_graph* g, const float* vectors)
+{
+    return guarded([&] {
+        REQUIRE(h && g && vectors, "import_flat: NULL argument");
+        REQUIRE(g->nlayers >= 1 && g->nlayers <= 64 && g->n >= 1 && g->d >= 1, "import_flat: empty graph");
+        REQUIRE(g->deg0 >= 1 && g->deg0 <= 64 && g->degu >= 1 && g->degu <= 64, "import_flat: degree out of range");
+        FlatGraph f;
+        f.n = g->n; f.d = g->d; f.nlayers = g->nlayers; f.deg0 = g->deg0; f.degu = g->degu;
+        f.up_off.assign(g->up_off, g->up_off + g->nlayers + 1);
+        REQUIRE(f.up_off[0] == 0 && f.up_off[1] == 0, "import_flat: up_off must start 0,0");
+        for (uint32_t l = 1; l < g->nlayers; l++) REQUIRE(f.up_off[l + 1] > f.up_off[l], "import_flat: up_off not increasing");
+        const uint32_t U = f.up_off[g->nlayers];
+        f.adj0.assign(g->adj0, g->adj0 + (size_t)g->n * g->deg0);
+        f.cnt0.assign(g->cnt0, g->cnt0 + g->n);
+        f.up_order.assign(g->up_order, g->up_order + U);
+        f.up_down.assign(g->up_down, g->up_down + U);
+        f.up_cnt.assign(g->up_cnt, g->up_cnt + U);
+        f.up_adj_slot.assign(g->up_adj_slot, g->up_adj_slot + (size_t)U * g->degu);
+        f.up_adj_order.assign(g->up_adj_order, g->up_adj_order + (size_t)U * g->degu);
+        f.ep_slot.assign(g->ep_slot, g->ep_slot + g->nlayers);
+        f.ep_order.assign(g->ep_order, g->ep_order + g->nlayers);
+        try { h->host.import_flat(f, vectors); }
+        catch (const std::invalid_argument& e) { g_err = e.what(); throw std::domain_error(e.what()); }
+    });
+}
+
+int hnsw_amd_export_flat(hnsw_amd_index* h, hnsw_amd_flat_graph* g, const float** vectors)
+{
+    return guarded([&] {
+        REQUIRE(h && g, "export_flat: NULL argument");
+        h->host.export_flat(h->exported);
+        const FlatGraph& f = h->exported;
+        g->n = f.n; g->d = f.d; g->nlayers = f.nlayers; g->deg0 = f.deg0; g->degu = f.degu;
+        g->adj0 = f.adj0.data(); g->cnt0 = f.cnt0.data(); g->up_off = f.up_off.data(); g->up_order = f.up_order.data();
+        g->up_down = f.up_down.data(); g->up_cnt = f.up_cnt.data(); g->up_adj_slot = f.up_adj_slot.data();
+        g->up_adj_order = f.up_adj_order.data(); g->ep_slot = f.ep_slot.data(); g->ep_order = f.ep_order.data();
+        if (vectors) *vectors = h->host.vector_data_.data();
+    });
+}
+
+int hnsw_amd_get_info(hnsw_amd_index* h, int32_t* M, int32_t* Mmax, int32_t* Mmax0, int32_t* efConstruction,
+                      uint32_t* vector_size, int32_t* max_node_count, int32_t* actual_node_count, uint32_t* nlayers)
+{
+    return guarded([&] {
+        REQUIRE(h, "get_info: index is NULL");
+        if (M) *M = h->host.M_;
+        if (Mmax) *Mmax = h->host.Mmax_;
+        if (Mmax0) *Mmax0 = h->host.Mmax0_;
+        if (efConstruction) *efConstruction = h->host.efConstruction_;
+        if (vector_size) *vector_size = h->host.vector_size_;
+        if (max_node_count) *max_node_count = h->host.max_node_count_;
+        if (actual_node_count) *actual_node_count = h->host.actual_node_count_;
+        if (nlayers) *nlayers = (uint32_t)h->host.layers_.size();
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,72 @@
+// Device-side (HBM) form of the index and the launch interface of the search kernels.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+
+#include "../../include/hnsw_amd.h"
+#include "hnsw_host.h"
+
+namespace hnsw_amd {
+
+// What a kernel needs to walk the graph; passed by value.  All pointers are device memory.
+struct DeviceGraph {
+    uint32_t n, d;
+    uint32_t row_stride;        // floats per stored row: d rounded up to a multiple of 32 (128-byte lines), zero filled
+    uint32_t nlayers, deg0, degu;
+    uint32_t top_ep_slot, top_ep_order;
+    const float* vectors;       // n x row_stride
+    const uint32_t* adj0;       // n x deg0, 0xFFFFFFFF padded (the live entries are a prefix)
+    const uint32_t* up_off;     // nlayers+1
+    const uint32_t* up_down;    // U
+    const uint32_t* up_adj_slot;   // U x degu
+    const uint32_t* up_adj_order;  // U x degu
+};
+
+// On-chip scratch configuration of one launch ("tier"): sizes of the per-query LDS structures.
+struct ScratchTier {
+    uint32_t hash_bits;   // visited set: 2^hash_bits slots of 4 bytes
+    uint32_t cap_c;       // candidate heap capacity (8-byte entries)
+};
+
+struct SearchArgs {
+    DeviceGraph g;
+    const float* queries;     // nq x d (unpadded rows)
+    const uint32_t* qmap;     // optional: block -> query index (retry launches); nullptr = identity
+    uint32_t nq_launch;       // blocks in this launch
+    uint32_t ef, out_k, flags;
+    uint32_t hash_bits, cap_c, cap_w;   // cap_w: ef+1 rounded up to even
+    uint32_t qpad;            // floats of the query copy in LDS (multiple of 64)
+    uint32_t* out_ids;        // nq x out_k
+    float* out_dist;          // nq x out_k
+    uint32_t* out_count;      // nq or nullptr
+    hnsw_amd_query_stats* stats;   // nq or nullptr
+    uint32_t* fail_count;     // device word: number of queries whose scratch overflowed in this launch
+    uint32_t* fail_list;      // their query indices
+};
+
+size_t search_lds_bytes(const SearchArgs& a);
+
+class DeviceIndex {
+public:
+    int device = -1;
+    uint64_t version = ~0ull;     // HostIndex::version_ this copy was made from
+    DeviceGraph g{};
+    // scratch for the retry protocol
+    uint32_t* d_fail = nullptr;       // [0] = count, [1..] list
+    uint32_t fail_cap = 0;
+    uint32_t* h_fail = nullptr;       // pinned host mirror of d_fail[0]
+
+    ~DeviceIndex();
+    void release();
+    void upload(const HostIndex& h, int device);
+    // Runs the batch (device pointers), re-running overflowed queries on larger tiers.
+    // Returns the number of re-run queries; throws on HIP errors / scratch exhaustion.
+    uint32_t search(const float* d_queries, uint32_t nq, int ef, uint32_t out_k, uint32_t flags, uint32_t* d_ids,
+                    float* d_dist, uint32_t* d_count, hnsw_amd_query_stats* d_stats, void* stream, bool sync_and_retry);
+
+private:
+    void* bufs_[8] = {};
+};
+
+}  // namespace hnsw_amd

@@ -1,0 +1,140 @@
+/* hnsw_amd.h — C ABI of the MI355X HNSW query engine (libhnsw_amd.so).
+ *
+ * The reference (RadimBaca/HNSW) has no FFI: its boundary is the public surface of
+ * `class HNSW` (src/hnsw.h:217-603) as used by its driver (src/main.cpp:197-293).
+ * Each entry point below is that surface flattened to C — plain pointers and sizes,
+ * status codes instead of exceptions — and names the reference member it replaces.
+ * include/hnsw_amd.hpp wraps these calls back into a `class HNSW` with the
+ * reference's member names.
+ *
+ * The search entry points run ONLY on the GPU (hand-written HIP kernels for gfx950);
+ * there is no CPU search path in this library.  Index construction (insert) runs on
+ * the host, as in the reference.
+ *
+ * Threading: calls on one index must be serialised by the caller (the reference
+ * object is not re-entrant either, src/hnsw.cpp:344,380).  Different indexes are
+ * independent.  All functions return HNSW_AMD_OK (0) or a negative error code;
+ * hnsw_amd_last_error() gives the message of the calling thread's last failure.
+ */
+#ifndef HNSW_AMD_H
+#define HNSW_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hnsw_amd_index hnsw_amd_index;
+
+enum {
+    HNSW_AMD_OK = 0,
+    HNSW_AMD_E_ARG = -1,      /* bad argument / index state */
+    HNSW_AMD_E_FULL = -2,     /* insert beyond max_node_count (reference: std::runtime_error, src/hnsw.cpp:176-179) */
+    HNSW_AMD_E_IO = -3,       /* file could not be opened / is malformed */
+    HNSW_AMD_E_HIP = -4,      /* a HIP runtime call failed */
+    HNSW_AMD_E_SCRATCH = -5,  /* a query outgrew the largest on-chip scratch configuration */
+    HNSW_AMD_E_GRAPH = -6     /* imported graph failed validation */
+};
+
+/* flags of the search entry points */
+enum {
+    HNSW_AMD_DIST_SSE = 0,        /* distance of the shipped build: first 16*floor(d/16) dims, 4 lane sums, fused
+                                     multiply-add (src/hnsw.h:334-383) */
+    HNSW_AMD_DIST_SCALAR = 1,     /* distance of a -DNO_MANUAL_VECTORIZATION build: all d dims, one running sum
+                                     (src/hnsw.h:387-400) */
+    HNSW_AMD_KEYS_INT32 = 0,      /* candidate heap keyed by int32-truncated distances, as the reference
+                                     (src/hnsw.cpp:727,767) */
+    HNSW_AMD_KEYS_FLOAT = 2       /* candidate heap keyed by the float distance (textbook HNSW; not the reference) */
+};
+
+/* Per-query counters, identical between this library and the CPU restatement used to
+ * test it.  They define the algorithmic HBM traffic of a query:
+ *   bytes = n_dist*4*d_used + 4*(sum_deg0 + sum_degu) + 4*d + 8*k                      */
+typedef struct {
+    uint32_t n_dist;        /* distance computations (one base-vector row fetched each) */
+    uint32_t n_expand;      /* layer-0 candidates expanded (one adjacency row each) */
+    uint32_t n_sweeps;      /* upper-layer neighbour-list sweeps */
+    uint32_t sum_deg0;      /* sum of degrees of the expanded layer-0 nodes */
+    uint32_t sum_degu;      /* sum of degrees of the swept upper-layer nodes */
+    uint32_t max_c;         /* largest size the candidate heap reached */
+    uint32_t n_visited0;    /* visited-set size after the layer-0 search */
+    uint32_t n_visited_up;  /* visited-set size after the upper-layer descent */
+} hnsw_amd_query_stats;
+
+/* Flat (pointer-free) graph: the reference's Layer/Node/Neighbors objects
+ * (src/layer.h:9-38, src/node.h:17-135) as arrays.  Neighbour order is preserved.
+ * Layer 0: slot == node_order.  Upper layers 1..nlayers-1 are concatenated, layer l
+ * owning slots [up_off[l], up_off[l+1]).  Padding value 0xFFFFFFFF. */
+typedef struct {
+    uint32_t n, d, nlayers, deg0, degu;
+    const uint32_t* adj0;         /* n x deg0 node_orders */
+    const uint32_t* cnt0;         /* n */
+    const uint32_t* up_off;       /* nlayers+1, up_off[0]=up_off[1]=0 */
+    const uint32_t* up_order;     /* node_order of each upper slot */
+    const uint32_t* up_down;      /* slot in the layer below (layer 1: node_order) */
+    const uint32_t* up_cnt;
+    const uint32_t* up_adj_slot;  /* U x degu: neighbour's slot inside the same layer */
+    const uint32_t* up_adj_order; /* U x degu: neighbour's node_order */
+    const uint32_t* ep_slot;      /* nlayers: entry point of each layer */
+    const uint32_t* ep_order;     /* nlayers */
+} hnsw_amd_flat_graph;
+
+const char* hnsw_amd_last_error(void);
+
+/* HNSW::HNSW(int M, int Mmax, int efConstruction) — src/hnsw.h:269-280 */
+int hnsw_amd_create(int M, int Mmax, int efConstruction, hnsw_amd_index** out);
+/* HNSW::~HNSW / HNSW::clean — src/hnsw.h:282-288, src/hnsw.cpp:22-32 */
+void hnsw_amd_destroy(hnsw_amd_index* h);
+/* HNSW::init(uint32_t vector_size, uint32_t max_node_count) — src/hnsw.cpp:3-20 */
+int hnsw_amd_init(hnsw_amd_index* h, uint32_t vector_size, uint32_t max_node_count);
+/* HNSW::insert(float* q) — src/hnsw.cpp:163-334.  Sequential, reproduces the reference's graph. */
+int hnsw_amd_insert(hnsw_amd_index* h, const float* q);
+/* The insert loop of the driver (src/main.cpp:207-210) for n rows.  threads <= 1: the same
+ * sequential inserts; threads > 1: concurrent inserts (a valid HNSW graph of the same
+ * construction rule, but not the reference's exact adjacency). */
+int hnsw_amd_insert_batch(hnsw_amd_index* h, const float* rows, uint32_t n, int threads);
+
+/* HNSW::aproximateKnn(float* q, int k, int ef) — src/hnsw.cpp:373-449.  The reference leaves
+ * its result in the public member W_ (up to ef entries, ascending squared-L2 distance; k is
+ * ignored, src/hnsw.cpp:373): here W_ is returned through out_ids/out_dist (room for ef
+ * entries each) and *out_count.  Runs on the GPU. */
+int hnsw_amd_aproximate_knn(hnsw_amd_index* h, const float* q, int k, int ef, uint32_t flags,
+                            uint32_t* out_ids, float* out_dist, uint32_t* out_count);
+/* The query loop of the driver (src/main.cpp:237-240, 291-294) as one batched call: nq
+ * queries (row-major nq x d, host memory), the first out_k (<= ef) entries of each query's
+ * W_ into out_ids/out_dist (nq x out_k; short rows padded with 0xFFFFFFFF / +inf),
+ * |W_| into out_count (may be NULL), counters into stats (nq entries, may be NULL). */
+int hnsw_amd_search_batch(hnsw_amd_index* h, const float* queries, uint32_t nq, int ef, uint32_t out_k,
+                          uint32_t flags, uint32_t* out_ids, float* out_dist, uint32_t* out_count,
+                          hnsw_amd_query_stats* stats);
+/* Same with every buffer already in device memory of the index's GPU; asynchronous on
+ * `stream` (a hipStream_t, NULL = default stream).  *retried (host, may be NULL) receives
+ * the number of queries that had to be re-run with a larger on-chip scratch; unless it is
+ * NULL the call synchronises the stream to learn it. */
+int hnsw_amd_search_batch_device(hnsw_amd_index* h, const float* d_queries, uint32_t nq, int ef, uint32_t out_k,
+                                 uint32_t flags, uint32_t* d_out_ids, float* d_out_dist, uint32_t* d_out_count,
+                                 hnsw_amd_query_stats* d_stats, void* stream, uint32_t* retried);
+
+/* HNSW::saveGraph / HNSW::loadGraph — src/hnsw.cpp:1178-1240, 1244-1311; same file format. */
+int hnsw_amd_save_graph(hnsw_amd_index* h, const char* filename);
+int hnsw_amd_load_graph(hnsw_amd_index* h, const char* filename);
+
+/* "Identical adjacency exported from the reference build": adopt a flat graph and its
+ * vectors (n x d row-major) instead of building; and the reverse.  The exported pointers
+ * stay owned by the index and valid until it is modified or destroyed. */
+int hnsw_amd_import_flat(hnsw_amd_index* h, const hnsw_amd_flat_graph* g, const float* vectors);
+int hnsw_amd_export_flat(hnsw_amd_index* h, hnsw_amd_flat_graph* g, const float** vectors);
+
+/* Copy (or refresh) the flat index into the HBM of `device`.  Search calls do this
+ * themselves when the index changed; calling it first keeps the upload out of timings. */
+int hnsw_amd_sync_device(hnsw_amd_index* h, int device);
+
+/* Public data members of the reference object that callers read (src/hnsw.h:221-236). */
+int hnsw_amd_get_info(hnsw_amd_index* h, int32_t* M, int32_t* Mmax, int32_t* Mmax0, int32_t* efConstruction,
+                      uint32_t* vector_size, int32_t* max_node_count, int32_t* actual_node_count, uint32_t* nlayers);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HNSW_AMD_H */

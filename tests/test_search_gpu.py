@@ -1,0 +1,98 @@
+"""GPU parity: the HIP search kernel, called through the C ABI, on the graphs exported from
+the reference build, against (a) the W_ the unmodified reference produced (golden fixtures)
+and (b) the CPU restatement (oracle) on the same inputs, counters included.
+
+Bar: every float distance bit for bit; ids identical except for permutations inside groups
+of exactly equal distance (the reference's final std::sort leaves their order open)."""
+import numpy as np
+import pytest
+
+from hnsw_amd import HNSW, capi
+from oracle import oracle
+from tests.helpers import Golden, assert_same_results, golden_names
+
+pytestmark = pytest.mark.gpu
+
+
+def _flags(g):
+    return (capi.DIST_SCALAR if g.dist_mode == 1 else capi.DIST_SSE) | capi.KEYS_INT32
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_kernel_matches_reference_W(name):
+    g = Golden(name)
+    h = HNSW(*g.meta["ctor"])
+    h.import_flat(g.graph, g.base)
+    h.flags = _flags(g)
+    for ef, (ids_ref, dist_ref, cnt_ref) in g.results.items():
+        ids, dist, cnt = h.search_batch(g.queries, ef)
+        assert np.array_equal(cnt, cnt_ref), f"{name} ef={ef}: |W_| differs"
+        assert_same_results(ids, dist, ids_ref, dist_ref, what=f"{name} ef={ef}")
+
+
+@pytest.mark.parametrize("name", ["int_d32_n2000", "unit_d100_n2000_sse", "unit_d100_n2000_scalar", "int_d16_n1000_m5"])
+@pytest.mark.parametrize("keys", ["int32", "float"])
+def test_kernel_matches_oracle_with_counters(name, keys):
+    g = Golden(name)
+    h = HNSW(*g.meta["ctor"])
+    h.import_flat(g.graph, g.base)
+    kflag, kmode = (capi.KEYS_FLOAT, oracle.KEYS_FLOAT) if keys == "float" else (capi.KEYS_INT32, oracle.KEYS_INT32)
+    dflag = capi.DIST_SCALAR if g.dist_mode == 1 else capi.DIST_SSE
+    idx = oracle.OracleIndex(g.graph, g.base)
+    for ef in (1, 7, 33, 128):
+        ids, dist, cnt, st = h.search_batch(g.queries, ef, flags=dflag | kflag, stats=True)
+        oi, od, oc, ost = idx.search(g.queries, ef, dist_mode=g.dist_mode, key_mode=kmode, stats=True)
+        assert np.array_equal(cnt, oc)
+        assert_same_results(ids, dist, oi, od, what=f"{name} ef={ef} keys={keys}")
+        for field in st.dtype.names:
+            assert np.array_equal(st[field], ost[field]), f"{name} ef={ef}: counter {field} differs"
+
+
+def test_top_k_is_a_prefix_of_W():
+    g = Golden("int_d128_n4000")
+    h = HNSW(*g.meta["ctor"])
+    h.import_flat(g.graph, g.base)
+    ids_full, dist_full, _ = h.search_batch(g.queries, 64)
+    ids, dist, cnt = h.search_batch(g.queries, 64, out_k=10)
+    assert np.array_equal(dist, dist_full[:, :10]) and np.array_equal(ids, ids_full[:, :10])
+    assert (cnt == 64).all()
+
+
+def test_aproximateKnn_fills_W_like_the_reference():
+    g = Golden("int_d32_n2000")
+    h = HNSW(*g.meta["ctor"])
+    h.import_flat(g.graph, g.base)
+    ids_ref, dist_ref, cnt_ref = g.results[10]
+    for i in range(5):
+        h.aproximateKnn(g.queries[i], 10, 10)
+        assert len(h.W_) == cnt_ref[i]
+        assert [w.distance for w in h.W_] == dist_ref[i].tolist()
+        assert sorted(w.node_order for w in h.W_) == sorted(ids_ref[i].tolist())
+
+
+def test_single_layer_and_tiny_graphs():
+    # fewer nodes than ef, one layer only: W_ holds every reachable node
+    rng = np.random.default_rng(5)
+    base = rng.integers(0, 50, size=(9, 16)).astype(np.float32)
+    h = HNSW(16, 16, 200)
+    h.init(16, 9)
+    h.insert_batch(base)
+    fg = h.export_flat()
+    q = rng.integers(0, 50, size=(4, 16)).astype(np.float32)
+    ids, dist, cnt = h.search_batch(q, 32)
+    oi, od, oc = oracle.OracleIndex(fg, base).search(q, 32)
+    assert np.array_equal(cnt, oc) and (cnt <= 9).all()
+    assert_same_results(ids, dist, oi, od, what="tiny")
+    assert (ids[:, 9:] == 0xFFFFFFFF).all() and np.isinf(dist[:, 9:]).all()
+
+
+def test_scratch_overflow_is_retried_transparently():
+    # a large ef on a small graph visits most nodes: tier 0 overflows for some queries
+    g = Golden("int_d128_n4000")
+    h = HNSW(*g.meta["ctor"])
+    h.import_flat(g.graph, g.base)
+    idx = oracle.OracleIndex(g.graph, g.base)
+    ids, dist, cnt = h.search_batch(g.queries, 200)
+    oi, od, oc = idx.search(g.queries, 200)
+    assert np.array_equal(cnt, oc)
+    assert_same_results(ids, dist, oi, od, what="ef=200")
