@@ -1,0 +1,279 @@
+#!/usr/bin/env python3
+"""Headline benchmark: batched HNSW k-NN search, QPS at recall@10 >= 0.95 on a SIFT-128-shaped
+1M-vector set (synthetic), one process per GPU.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one pass of the search over the whole query batch (10 000 queries resident in HBM).
+N > 1: the base set is split into N contiguous shards, each rank builds and searches its own
+sub-graph, the per-shard top-k lists are all-gathered over RCCL and merged on the device.
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (spec)
+
+
+def log(*a):
+    print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=1_000_000, help="base vectors (whole job)")
+    ap.add_argument("--nq", type=int, default=10_000)
+    ap.add_argument("--kind", default="sift")
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--ef", type=int, default=0, help="0 = smallest ef of the reference sweep with recall@10 >= target")
+    ap.add_argument("--target-recall", type=float, default=0.95)
+    ap.add_argument("--build-threads", type=int, default=16)
+    ap.add_argument("--cpu-baseline", default="port", choices=["port", "reference", "none"])
+    ap.add_argument("--cpu-sample", type=int, default=4000)
+    ap.add_argument("--keys", default="int32", choices=["int32", "float"])
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from hnsw_amd import HNSW, capi, datagen, harness
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the search has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    d = datagen.KINDS[args.kind]
+    k = args.k
+    # ---- shard of the base set, queries ----
+    lo = rank * args.n // world
+    hi = (rank + 1) * args.n // world
+    t0 = time.time()
+    base = datagen.make(args.kind, hi - lo, seed=1, stream=0, row0=lo)
+    queries = datagen.make(args.kind, args.nq, seed=1, stream=1)
+    log(f"rank {rank}: data {base.shape} in {time.time() - t0:.1f}s")
+
+    # ---- build (host, concurrent inserts) or load from the cache directory ----
+    h = HNSW(16, 16, 200, device=local_rank)
+    cache = os.environ.get("HNSW_AMD_BENCH_CACHE")
+    cpath = os.path.join(cache, f"{args.kind}_n{args.n}_s{world}_r{rank}.npz") if cache else None
+    t0 = time.time()
+    if cpath and os.path.exists(cpath):
+        from hnsw_amd.flatgraph import FlatGraph
+        h.import_flat(FlatGraph.from_npz(np.load(cpath)), base)
+        log(f"rank {rank}: graph loaded from {cpath} in {time.time() - t0:.1f}s")
+    else:
+        h.init(d, hi - lo)
+        h.insert_batch(base, threads=args.build_threads)
+        log(f"rank {rank}: built {hi - lo} vectors with {args.build_threads} threads in {time.time() - t0:.1f}s")
+        if cpath:
+            os.makedirs(cache, exist_ok=True)
+            np.savez(cpath, **h.export_flat().to_npz_dict())
+    build_s = time.time() - t0
+    h.sync_device(local_rank)
+
+    # ---- device buffers ----
+    q_t = torch.from_numpy(queries).to(dev)
+    nq = args.nq
+    EFMAX = 200
+    ids_t = torch.empty((nq, EFMAX), dtype=torch.int32, device=dev)
+    dist_t = torch.empty((nq, EFMAX), dtype=torch.float32, device=dev)
+    cnt_t = torch.empty((nq,), dtype=torch.int32, device=dev)
+    stats_t = torch.empty((nq, 8), dtype=torch.int32, device=dev)
+    flags = capi.DIST_SSE | (capi.KEYS_FLOAT if args.keys == "float" else capi.KEYS_INT32)
+    offsets = np.array([r * args.n // world for r in range(world)], dtype=np.uint32)
+    if world > 1:
+        g_dist = torch.empty((world, nq, k), dtype=torch.float32, device=dev)
+        g_ids = torch.empty((world, nq, k), dtype=torch.int32, device=dev)
+    out_ids = torch.empty((nq, k), dtype=torch.int32, device=dev)
+    out_dist = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    L = capi.lib()
+
+    def step(ef, out_k, want_stats=False):
+        """One pass over the query batch; leaves the final top-out_k (global ids) in out_ids/out_dist."""
+        stream = torch.cuda.current_stream().cuda_stream
+        if world == 1:
+            h.search_batch_device(q_t.data_ptr(), nq, ef, out_k, out_ids.data_ptr(), out_dist.data_ptr(), cnt_t.data_ptr(),
+                                  stats_t.data_ptr() if want_stats else 0, stream, flags)
+            return
+        h.search_batch_device(q_t.data_ptr(), nq, ef, out_k, ids_t.data_ptr(), dist_t.data_ptr(), cnt_t.data_ptr(),
+                              stats_t.data_ptr() if want_stats else 0, stream, flags)
+        loc_d = dist_t.view(-1)[: nq * out_k].view(nq, out_k)
+        loc_i = ids_t.view(-1)[: nq * out_k].view(nq, out_k)
+        dist.all_gather_into_tensor(g_dist.view(-1), loc_d.reshape(-1))
+        dist.all_gather_into_tensor(g_ids.view(-1), loc_i.reshape(-1))
+        capi.check(L.hnsw_amd_merge_topk_device(g_dist.data_ptr(), g_ids.data_ptr(), capi.u32(offsets), world, nq, out_k, out_k,
+                                                out_ids.data_ptr(), out_dist.data_ptr(), stream))
+
+    # ---- exact ground truth (brute force on the GPU over every shard, merged) ----
+    t0 = time.time()
+    base_t = torch.from_numpy(base).to(dev)
+    gd, gi = harness.exact_topk_torch(base_t, q_t, k + 1, id_offset=int(offsets[rank]))
+    del base_t
+    if world > 1:
+        all_d = [torch.empty_like(gd) for _ in range(world)]
+        all_i = [torch.empty_like(gi) for _ in range(world)]
+        dist.all_gather(all_d, gd)
+        dist.all_gather(all_i, gi)
+        cd, ci = torch.cat(all_d, 1), torch.cat(all_i, 1)
+        _, sel = torch.topk(cd, k + 1, dim=1, largest=False)
+        gi = torch.gather(ci, 1, sel)
+    gt = gi.cpu().numpy()
+    log(f"ground truth in {time.time() - t0:.1f}s")
+
+    # ---- ef: the reference's sweep, smallest ef reaching the target recall@10 ----
+    sweep = []
+    ef_pick = args.ef
+    for ef in ([args.ef] if args.ef else harness.REFERENCE_EF_SWEEP):
+        step(ef, k)
+        torch.cuda.synchronize()
+        ids = out_ids.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+        r = harness.recall_at_k(ids, gt, k)
+        sweep.append((ef, round(r, 4)))
+        if not args.ef and r >= args.target_recall:
+            ef_pick = ef
+            break
+    if not ef_pick:
+        ef_pick = harness.REFERENCE_EF_SWEEP[-1]
+    ef = ef_pick
+    log(f"ef sweep {sweep} -> ef={ef}")
+
+    # ---- per-query counters at the operating point -> algorithmic bytes per launch ----
+    step(ef, k, want_stats=True)
+    torch.cuda.synchronize()
+    st = stats_t.cpu().numpy().view(np.uint32).reshape(nq, 8).copy().view(capi.STATS_DTYPE).reshape(nq)
+    bytes_per_launch = int(harness.algorithmic_bytes(st, d, d & ~15, k).sum())
+    ids_final = out_ids.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    # top-(k+1) for the reference's own "Precision" figure
+    prec_ref = None
+    if world == 1:
+        kk_ids = torch.empty((nq, k + 1), dtype=torch.int32, device=dev)
+        kk_d = torch.empty((nq, k + 1), dtype=torch.float32, device=dev)
+        h.search_batch_device(q_t.data_ptr(), nq, max(ef, k + 1), k + 1, kk_ids.data_ptr(), kk_d.data_ptr(), 0, 0,
+                              torch.cuda.current_stream().cuda_stream, flags)
+        torch.cuda.synchronize()
+        prec_ref = harness.reference_precision(kk_ids.cpu().numpy().astype(np.int64) & 0xFFFFFFFF, gt, k)
+    recall = harness.recall_at_k(ids_final, gt, k)
+
+    # ---- timed region ----
+    for _ in range(args.warmup):
+        step(ef, k)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record()
+        step(ef, k)
+        ev[i][1].record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    step_ms_dev = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    qps = nq * args.steps / elapsed
+
+    # search-kernel time alone (events around the search call only; N=1: the whole step)
+    if world == 1:
+        kern_ms = step_ms_dev
+    else:
+        kev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
+        for a, b in kev:
+            a.record()
+            h.search_batch_device(q_t.data_ptr(), nq, ef, k, ids_t.data_ptr(), dist_t.data_ptr(), cnt_t.data_ptr(), 0,
+                                  torch.cuda.current_stream().cuda_stream, flags)
+            b.record()
+        torch.cuda.synchronize()
+        kern_ms = float(np.mean([a.elapsed_time(b) for a, b in kev]))
+    achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
+
+    # ---- CPU baseline on the host cores (rank 0, N=1 only): bounded sample, the reference's protocol ----
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_baseline != "none":
+        ns = min(args.cpu_sample, nq)
+        if args.cpu_baseline == "reference":
+            drv = os.path.join(ROOT, "oracle", "_ref", "ref_driver_sse")
+            with tempfile.TemporaryDirectory() as tmp:
+                gpath, qpath = os.path.join(tmp, "g.bin"), os.path.join(tmp, "q.bin")
+                h.saveGraph(gpath)
+                queries[:ns].tofile(qpath)
+                out = subprocess.run([drv, "ltime", gpath, "16", "16", "200", qpath, str(ns), str(ef), "30"],
+                                     capture_output=True, text=True, check=True).stderr
+            rec = json.loads(out.strip().splitlines()[-1])
+            cpu = {"value": round(rec["qps"], 1), "unit": "queries/s", "cores": 1, "kind": "reference",
+                   "sample": f"first {ns} queries, ef={ef}, min of {rec['passes']} passes; unmodified reference binary, "
+                             f"index read by its own loadGraph from the file this library saved"}
+        else:
+            from oracle import oracle
+            idx = oracle.OracleIndex(h.export_flat(), base)
+            best = 1e30
+            for _ in range(3):
+                t0 = time.perf_counter()
+                o_ids, o_d, _ = idx.search(queries[:ns], ef, out_k=k, threads=1)
+                best = min(best, time.perf_counter() - t0)
+            nt = min(16, os.cpu_count() or 1)
+            t0 = time.perf_counter()
+            idx.search(queries, ef, out_k=k, threads=nt)
+            mt = time.perf_counter() - t0
+            same = bool(np.array_equal(o_d, out_dist.cpu().numpy()[:ns]))
+            cpu = {"value": round(ns / best, 1), "unit": "queries/s", "cores": 1, "kind": "port",
+                   "sample": f"first {ns} queries, ef={ef}, min of 3 passes, 1 thread (CPU restatement, bit-equal to the reference)",
+                   "mt": {"value": round(nq / mt, 1), "cores": nt},
+                   "gpu_distances_bit_equal_on_sample": same}
+
+    if rank == 0:
+        out = {
+            "metric": "queries/s at recall@10>=0.95, HNSW search, SIFT-128-shaped 1M base / 10k queries",
+            "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.kind}-{d} synthetic, n={args.n}, nq={nq}, M=16, efConstruction=200, ef={ef}, k={k}, "
+                                   f"keys={args.keys}" + (f", {world} shards + RCCL all-gather + device merge" if world > 1 else ""),
+                       "ef": ef, "recall_at_10": round(recall, 4), "reference_precision_top11": prec_ref,
+                       "ef_sweep": sweep, "build_s": round(build_s, 1), "build_threads": args.build_threads},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "hnsw_search_kernel", "kernel_ms": round(kern_ms, 4),
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "bytes_per_query": round(bytes_per_launch / nq, 1)},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -49,6 +49,8 @@ SYMBOLS = {
     "hnsw_amd_import_flat": (C.c_int, [C.c_void_p, C.POINTER(FlatGraphC), _f32p]),
     "hnsw_amd_export_flat": (C.c_int, [C.c_void_p, C.POINTER(FlatGraphC), C.POINTER(_f32p)]),
     "hnsw_amd_sync_device": (C.c_int, [C.c_void_p, C.c_int]),
+    "hnsw_amd_merge_topk_device": (C.c_int, [C.c_void_p, C.c_void_p, _u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                             C.c_void_p, C.c_void_p, C.c_void_p]),
     "hnsw_amd_get_info": (C.c_int, [C.c_void_p, _i32p, _i32p, _i32p, _i32p, _u32p, _i32p, _i32p, _u32p]),
 }
 

@@ -15,6 +15,11 @@
 
 using namespace hnsw_amd;
 
+namespace hnsw_amd {
+void merge_topk(const float* d_dist, const uint32_t* d_ids, const uint32_t* shard_offset, uint32_t S, uint32_t nq, uint32_t k,
+                uint32_t out_k, uint32_t* d_out_ids, float* d_out_dist, void* stream);
+}
+
 struct hnsw_amd_index {
     HostIndex host;
     DeviceIndex dev;
@@ -211,6 +216,15 @@ int hnsw_amd_export_flat(hnsw_amd_index* h, hnsw_amd_flat_graph* g, const float*
         g->up_down = f.up_down.data(); g->up_cnt = f.up_cnt.data(); g->up_adj_slot = f.up_adj_slot.data();
         g->up_adj_order = f.up_adj_order.data(); g->ep_slot = f.ep_slot.data(); g->ep_order = f.ep_order.data();
         if (vectors) *vectors = h->host.vector_data_.data();
+    });
+}
+
+int hnsw_amd_merge_topk_device(const float* d_dist, const uint32_t* d_ids, const uint32_t* shard_offset, uint32_t n_shards,
+                               uint32_t nq, uint32_t k, uint32_t out_k, uint32_t* d_out_ids, float* d_out_dist, void* stream)
+{
+    return guarded([&] {
+        REQUIRE(d_dist && d_ids && shard_offset && d_out_ids && d_out_dist, "merge_topk_device: NULL argument");
+        merge_topk(d_dist, d_ids, shard_offset, n_shards, nq, k, out_k, d_out_ids, d_out_dist, stream);
     });
 }
 

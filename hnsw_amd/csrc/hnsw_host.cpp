@@ -285,16 +285,19 @@ void HostIndex::link(int layer, uint32_t new_slot, uint32_t id, const std::vecto
 {
     LayerStore& L = layers_[layer];
     const uint32_t cap = layer == 0 ? (uint32_t)Mmax0_ : (uint32_t)Mmax_;
+    // The new node's own list first: nothing points at the node yet, so no other thread can
+    // touch it (the reference appends to it inside the loop below, with the same outcome).
+    {
+        SpinGuard g(MT ? &locks_[layer][new_slot] : nullptr);
+        if (R.size() > L.deg) throw std::logic_error("link: selected more neighbours than a list holds");
+        for (size_t i = 0; i < R.size(); i++) {
+            size_t at = (size_t)new_slot * L.deg + i;
+            L.nb_slot[at] = R[i].slot; L.nb_order[at] = R[i].node_order; L.nb_dist[at] = R[i].distance;
+        }
+        L.cnt[new_slot] = (uint32_t)R.size();
+    }
     for (size_t i = 0; i < R.size(); i++) {
         const Neighbor& e = R[i];
-        {
-            SpinGuard g(MT ? &locks_[layer][new_slot] : nullptr);
-            uint32_t k = L.cnt[new_slot];
-            if (k >= L.deg) throw std::logic_error("link: selected more neighbours than a list holds");
-            size_t at = (size_t)new_slot * L.deg + k;
-            L.nb_slot[at] = e.slot; L.nb_order[at] = e.node_order; L.nb_dist[at] = e.distance;
-            L.cnt[new_slot] = k + 1;
-        }
         SpinGuard g(MT ? &locks_[layer][e.slot] : nullptr);
         const size_t base = (size_t)e.slot * L.deg;
         uint32_t ecnt = L.cnt[e.slot];

@@ -11,6 +11,11 @@
 //   ref_driver query <base.bin> <n> <d> <M> <Mmax> <efC> <queries.bin> <nq> <results.out> <ef> [<ef>...]
 //   ref_driver time  <base.bin> <n> <d> <M> <Mmax> <efC> <queries.bin> <nq> <ef> <seconds>
 //
+//   ref_driver lquery <graph.savegraph> <M> <Mmax> <efC> <queries.bin> <nq> <results.out> <ef> [<ef>...]
+//   ref_driver ltime  <graph.savegraph> <M> <Mmax> <efC> <queries.bin> <nq> <ef> <seconds>
+//
+// "lquery"/"ltime" read the index with the reference's own HNSW::loadGraph (from a file in its
+// saveGraph format, e.g. one written by libhnsw_amd.so) instead of building it.
 // "query" and "time" build the index first (the build is deterministic: levels
 // come from rand() with the default seed, reference src/hnsw.cpp:165).
 //
@@ -72,9 +77,60 @@ static void dump_graph(HNSW& h, uint32_t n, const char* path) {
     fclose(f);
 }
 
+static int run_queries(HNSW& h, uint32_t d, const char* qpath, uint32_t nq, const char* out, int argc, char** argv, int first_ef) {
+    auto q = read_floats(qpath, (size_t)nq * d);
+    FILE* f = fopen(out, "wb");
+    if (!f) return 2;
+    w32(f, 0x31535248u); w32(f, nq); w32(f, (uint32_t)(argc - first_ef));
+    for (int a = first_ef; a < argc; a++) {
+        int ef = atoi(argv[a]);
+        w32(f, (uint32_t)ef);
+        for (uint32_t i = 0; i < nq; i++) {
+            h.aproximateKnn(&q[(size_t)i * d], 10, ef);
+            w32(f, (uint32_t)h.W_.size());
+            for (auto& e : h.W_) w32(f, e.node_order);
+            for (auto& e : h.W_) fwrite(&e.distance, 4, 1, f);
+        }
+    }
+    fclose(f);
+    return 0;
+}
+
+// the reference's protocol (src/main.cpp:285-304): passes over all queries, minimum kept
+static int run_timing(HNSW& h, uint32_t d, const char* qpath, uint32_t nq, int ef, double budget) {
+    auto q = read_floats(qpath, (size_t)nq * d);
+    double best = 1e30; int passes = 0;
+    auto start = std::chrono::steady_clock::now();
+    do {
+        auto a = std::chrono::steady_clock::now();
+        for (uint32_t i = 0; i < nq; i++) h.aproximateKnn(&q[(size_t)i * d], 10, ef);
+        auto b = std::chrono::steady_clock::now();
+        best = std::min(best, std::chrono::duration<double>(b - a).count());
+        passes++;
+    } while (passes < 3 && std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count() < budget);
+    fprintf(stderr, "{\"ref_time_s\": %.6f, \"nq\": %u, \"ef\": %d, \"passes\": %d, \"qps\": %.1f}\n",
+            best, nq, ef, passes, nq / best);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     if (argc < 9) { fprintf(stderr, "usage: see header of ref_driver.cpp\n"); return 2; }
     std::string mode = argv[1];
+    if (mode == "lquery" || mode == "ltime") {
+        HNSW h(atoi(argv[3]), atoi(argv[4]), atoi(argv[5]));
+        fflush(stdout);
+        FILE* devnull = freopen("/dev/null", "w", stdout);
+        (void)devnull;
+        h.loadGraph(argv[2]);
+        if (h.layers_.empty()) { fprintf(stderr, "loadGraph(%s) failed\n", argv[2]); return 2; }
+        uint32_t nq = (uint32_t)atoll(argv[7]);
+        if (mode == "lquery") {
+            if (argc < 10) return 2;
+            return run_queries(h, h.vector_size_, argv[6], nq, argv[8], argc, argv, 9);
+        }
+        if (argc < 10) return 2;
+        return run_timing(h, h.vector_size_, argv[6], nq, atoi(argv[8]), atof(argv[9]));
+    }
     const char* base_path = argv[2];
     uint32_t n = (uint32_t)atoll(argv[3]), d = (uint32_t)atoll(argv[4]);
     int M = atoi(argv[5]), Mmax = atoi(argv[6]), efC = atoi(argv[7]);
@@ -98,43 +154,11 @@ int main(int argc, char** argv) {
     }
     if (mode == "query") {
         if (argc < 12) return 2;
-        uint32_t nq = (uint32_t)atoll(argv[9]);
-        auto q = read_floats(argv[8], (size_t)nq * d);
-        FILE* f = fopen(argv[10], "wb");
-        if (!f) return 2;
-        w32(f, 0x31535248u); w32(f, nq); w32(f, (uint32_t)(argc - 11));
-        for (int a = 11; a < argc; a++) {
-            int ef = atoi(argv[a]);
-            w32(f, (uint32_t)ef);
-            for (uint32_t i = 0; i < nq; i++) {
-                h.aproximateKnn(&q[(size_t)i * d], 10, ef);
-                w32(f, (uint32_t)h.W_.size());
-                for (auto& e : h.W_) w32(f, e.node_order);
-                for (auto& e : h.W_) fwrite(&e.distance, 4, 1, f);
-            }
-        }
-        fclose(f);
-        return 0;
+        return run_queries(h, d, argv[8], (uint32_t)atoll(argv[9]), argv[10], argc, argv, 11);
     }
     if (mode == "time") {
         if (argc < 12) return 2;
-        uint32_t nq = (uint32_t)atoll(argv[9]);
-        auto q = read_floats(argv[8], (size_t)nq * d);
-        int ef = atoi(argv[10]);
-        double budget = atof(argv[11]);
-        // the reference's protocol (src/main.cpp:285-304): passes over all queries, minimum kept
-        double best = 1e30; int passes = 0;
-        auto start = std::chrono::steady_clock::now();
-        do {
-            auto a = std::chrono::steady_clock::now();
-            for (uint32_t i = 0; i < nq; i++) h.aproximateKnn(&q[(size_t)i * d], 10, ef);
-            auto b = std::chrono::steady_clock::now();
-            best = std::min(best, std::chrono::duration<double>(b - a).count());
-            passes++;
-        } while (passes < 3 && std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count() < budget);
-        fprintf(stderr, "{\"ref_time_s\": %.6f, \"nq\": %u, \"ef\": %d, \"passes\": %d, \"qps\": %.1f}\n",
-                best, nq, ef, passes, nq / best);
-        return 0;
+        return run_timing(h, d, argv[8], (uint32_t)atoll(argv[9]), atoi(argv[10]), atof(argv[11]));
     }
     return 2;
 }
