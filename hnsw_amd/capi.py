@@ -11,11 +11,13 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhnsw_amd.so")
+# HNSW_AMD_LIB: load another build of the same library (e.g. the phase-timing diagnostic build)
+LIB_PATH = os.environ.get("HNSW_AMD_LIB") or os.path.join(_HERE, "libhnsw_amd.so")
 
 OK, E_ARG, E_FULL, E_IO, E_HIP, E_SCRATCH, E_GRAPH = 0, -1, -2, -3, -4, -5, -6
 DIST_SSE, DIST_SCALAR = 0, 1
 KEYS_INT32, KEYS_FLOAT = 0, 2
+W_STD_HEAP = 4
 
 _u32p = C.POINTER(C.c_uint32)
 _f32p = C.POINTER(C.c_float)

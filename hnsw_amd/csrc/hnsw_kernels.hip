@@ -138,6 +138,106 @@ __device__ __forceinline__ void c_pop(uint2* a, uint32_t n)
     a[hole] = v;
 }
 
+// ---------------------------------------------------------------------------------------
+// The same two libstdc++ routines executed by the whole wavefront in a constant number of
+// LDS round trips instead of one per tree level.  They leave the array exactly as
+// std::push_heap / std::pop_heap do:
+//  - push: the new element climbs the fixed chain of ancestors of index n-1 while
+//    comp(ancestor, value); lane k owns ancestor k, one ballot gives the climb length.
+//  - pop: __adjust_heap first walks the hole from the root to a leaf choosing, at every
+//    node, a child by comparing the two SIBLINGS only (never the moving value), so every
+//    node's choice can be evaluated at once (one ballot per 64 internal nodes) and the
+//    walk becomes bit tests; then the saved last element climbs back up that same path
+//    (again one ballot).  Lane k owns step k of the path.
+// Both are called with wave-uniform arguments by all 64 lanes.
+// ---------------------------------------------------------------------------------------
+struct WOrder {   // comp(a,b) = a.dist < b.dist
+    static __device__ __forceinline__ bool before(uint2 a, uint2 b) { return __uint_as_float(a.x) < __uint_as_float(b.x); }
+};
+struct COrder {   // comp(a,b) = a.key > b.key
+    static __device__ __forceinline__ bool before(uint2 a, uint2 b) { return (int32_t)a.x > (int32_t)b.x; }
+};
+
+// Maximum of an unsigned value over the 64 lanes with DPP moves (no LDS round trips):
+// within quads, half rows and rows, then across the four rows; the result is read from lane 63.
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t x)
+{
+    uint32_t y;
+    y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0xB1, 0xF, 0xF, false); x = x > y ? x : y;    // quad_perm [1,0,3,2]
+    y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x4E, 0xF, 0xF, false); x = x > y ? x : y;    // quad_perm [2,3,0,1]
+    y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x141, 0xF, 0xF, false); x = x > y ? x : y;   // row_half_mirror
+    y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x140, 0xF, 0xF, false); x = x > y ? x : y;   // row_mirror
+    y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x142, 0xA, 0xF, false); x = x > y ? x : y;   // row_bcast15 -> rows 1,3
+    y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x143, 0xC, 0xF, false); x = x > y ? x : y;   // row_bcast31 -> rows 2,3
+    return __builtin_amdgcn_readlane(x, 63);
+}
+
+constexpr uint32_t kWaveHeapMax = 513;   // larger heaps use the one-lane routines
+
+template <class Ord>
+__device__ __forceinline__ void heap_push_wave(uint2* a, uint32_t n /* size including the new element */, uint2 v, int lane)
+{
+    const uint32_t depth = 31u - (uint32_t)__clz((int)n);        // levels above index n-1
+    uint2 x = make_uint2(0, 0);
+    bool c = false;
+    if ((uint32_t)lane < depth) { x = a[(n >> (lane + 1)) - 1]; c = Ord::before(x, v); }
+    const unsigned long long m = __ballot(c);
+    const uint32_t t = (uint32_t)__builtin_ctzll(~m);            // ancestors that move down
+    if ((uint32_t)lane < t) a[(n >> lane) - 1] = x;
+    if ((uint32_t)lane == t) a[(n >> t) - 1] = v;
+}
+
+// Returns the new root (valid when n > 1).
+template <class Ord>
+__device__ __forceinline__ uint2 heap_pop_wave(uint2* a, uint32_t n /* size before the pop */, int lane)
+{
+    const uint32_t len = n - 1;
+    const uint2 v = a[len];
+    const uint32_t nint = (len - 1) >> 1;      // nodes with both children inside [0, len)
+    unsigned long long m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+    {
+        bool l0 = false, l1 = false, l2 = false, l3 = false;
+        uint32_t i = lane;
+        if (i < nint) l0 = Ord::before(a[2 * i + 2], a[2 * i + 1]);
+        if (nint > 64)  { i = lane + 64;  if (i < nint) l1 = Ord::before(a[2 * i + 2], a[2 * i + 1]); }
+        if (nint > 128) { i = lane + 128; if (i < nint) l2 = Ord::before(a[2 * i + 2], a[2 * i + 1]); }
+        if (nint > 192) { i = lane + 192; if (i < nint) l3 = Ord::before(a[2 * i + 2], a[2 * i + 1]); }
+        m0 = __ballot(l0);
+        if (nint > 64) m1 = __ballot(l1);
+        if (nint > 128) m2 = __ballot(l2);
+        if (nint > 192) m3 = __ballot(l3);
+    }
+    uint32_t cur = 0, d = 0, my_from = 0, my_to = 0;
+    while (cur < nint) {
+        const uint32_t w = cur >> 6;
+        const unsigned long long mm = w == 0 ? m0 : (w == 1 ? m1 : (w == 2 ? m2 : m3));
+        const uint32_t takes_left = (uint32_t)(mm >> (cur & 63)) & 1u;
+        const uint32_t nxt = 2 * cur + 2 - takes_left;
+        if ((uint32_t)lane == d) { my_from = nxt; my_to = cur; }
+        cur = nxt; d++;
+    }
+    if ((len & 1u) == 0 && cur == (len - 2) >> 1) {      // a last node with a left child only
+        const uint32_t nxt = 2 * cur + 1;
+        if ((uint32_t)lane == d) { my_from = nxt; my_to = cur; }
+        cur = nxt; d++;
+    }
+    uint2 x = make_uint2(0, 0);
+    bool c = false;
+    if ((uint32_t)lane < d) { x = a[my_from]; c = Ord::before(x, v); }
+    const unsigned long long cm = __ballot(c);
+    uint32_t s = 0;                                       // path elements (from the leaf up) that stay put
+    if (d > 0) { s = (uint32_t)__builtin_clzll(~(cm << (64 - d))); if (s > d) s = d; }
+    const uint32_t moved = d - s;
+    if ((uint32_t)lane < moved) a[my_to] = x;
+    if (s == 0) { if (lane == 0) a[cur] = v; }
+    else if ((uint32_t)lane == moved) a[my_to] = v;
+    // new root: the first path element if it moved up, else the re-inserted value
+    uint2 root;
+    root.x = moved > 0 ? rfl(x.x) : v.x;
+    root.y = moved > 0 ? rfl(x.y) : v.y;
+    return root;
+}
+
 // Exact visited set: open addressing, linear probing, one LDS compare-and-swap per probe.
 // Returns true when `id` was not in the set (and now is).
 __device__ __forceinline__ bool visited_insert(uint32_t* hash, uint32_t mask, uint32_t shift, uint32_t id)
@@ -151,6 +251,16 @@ __device__ __forceinline__ bool visited_insert(uint32_t* hash, uint32_t mask, ui
     }
 }
 
+// Diagnostic build only (-DHNSW_DIAG): the counters struct is overwritten with cycle sums
+// per phase (s_memtime), never in the shipped library.
+#ifdef HNSW_DIAG
+#define DIAG_STAMP(var) unsigned long long var = __builtin_amdgcn_s_memtime()
+#define DIAG_ADD(acc, a, b) acc += (uint32_t)((b) - (a))
+#else
+#define DIAG_STAMP(var)
+#define DIAG_ADD(acc, a, b)
+#endif
+
 struct WaveCtx {
     float* tile;          // kTileDwords
     float* qs;            // qpad floats, zero padded
@@ -163,93 +273,148 @@ struct WaveCtx {
     uint32_t nseg;        // ceil(d_eff / 64)
     uint32_t d4;          // scalar mode: dims whose square is rounded before the add
     int lane;
+#ifdef HNSW_DIAG
+    mutable uint32_t cy_load = 0, cy_chain = 0, cy_fin = 0;
+#endif
 };
 
-// Distances from the query to the rows nb_id[0..m) -> nb_dist[0..m).  m <= 64, wave-uniform.
+struct RowRegs { float4 r[4][2]; };    // one lane's share of 16 rows x 2 segments (128 dims)
+
+// Issue the loads of rows nb_id[b0 .. b0+16) for segments s0, s0+1: lane (h, c) takes the
+// 16-byte chunk c of row 4g+h for g = 0..3, so one instruction reads 256 contiguous bytes of
+// each of 4 rows.
+__device__ __forceinline__ void load_rows(const WaveCtx& w, uint32_t m, uint32_t b0, uint32_t s0, RowRegs& R)
+{
+    const int h = w.lane >> 4, c = w.lane & 15;
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const uint32_t r = b0 + 4 * g + h;
+        const bool ok = r < m;
+        const uint32_t id = ok ? w.nb_id[r] : 0u;
+        const float* rp = w.vectors + (size_t)id * w.row_stride + c * 4;
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            const uint32_t e0 = (s0 + s) * kSeg + c * 4;
+            R.r[g][s] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok && e0 < w.d_eff) R.r[g][s] = *reinterpret_cast<const float4*>(rp + (s0 + s) * kSeg);
+        }
+    }
+}
+
+// Differences to the query -> transposition tile -> the per-(row, lane-sum) chains, for the
+// segments s0, s0+1 held in R.  Returns the running sum of this lane's chain.
 // SCALAR=false: the reference's SSE loop order (4 lane sums, fma, left-to-right final add).
 // SCALAR=true : the reference's scalar loop as its -DNO_MANUAL_VECTORIZATION build runs it:
 //               one running sum; squares rounded before the add for the first 4*(d/4)
 //               dims, fused multiply-add for the last d%4.
 template <bool SCALAR>
+__device__ __forceinline__ float chain_rows(const WaveCtx& w, uint32_t s0, const RowRegs& R, float acc)
+{
+    const int h = w.lane >> 4, c = w.lane & 15;     // loader role
+    const int cr = w.lane >> 2, cj = w.lane & 3;    // chain role: row cr of the batch, lane-sum cj
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        if (s0 + s < w.nseg) {
+            const uint32_t seg = s0 + s;
+            const uint32_t e0 = seg * kSeg + c * 4;
+            const float4 qv = *reinterpret_cast<const float4*>(w.qs + e0);
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const float4 v = R.r[g][s];
+                float4 t;
+                t.x = v.x - qv.x; t.y = v.y - qv.y; t.z = v.z - qv.z; t.w = v.w - qv.w;
+                if (SCALAR && e0 < w.d4) { t.x = t.x * t.x; t.y = t.y * t.y; t.z = t.z * t.z; t.w = t.w * t.w; }
+                *reinterpret_cast<float4*>(w.tile + (4 * g + h) * kTileStride + c * 4) = t;
+            }
+            __syncthreads();
+            const uint32_t left = w.d_eff - seg * kSeg;          // dims of this segment
+            if (!SCALAR) {
+                const uint32_t steps = left >= kSeg ? 16u : (left >> 2);
+                const float* tp = w.tile + cr * kTileStride + cj;
+                if (steps == 16) {
+#pragma unroll
+                    for (int t = 0; t < 16; t++) { float x = tp[4 * t]; acc = __builtin_fmaf(x, x, acc); }
+                } else {
+                    for (uint32_t t = 0; t < steps; t++) { float x = tp[4 * t]; acc = __builtin_fmaf(x, x, acc); }
+                }
+            } else if (cj == 0) {
+                const uint32_t steps = left >= kSeg ? (uint32_t)kSeg : left;
+                const float* tp = w.tile + cr * kTileStride;
+                for (uint32_t t = 0; t < steps; t++) {
+                    float x = tp[t];
+                    if (seg * kSeg + t < w.d4) acc = acc + x; else acc = __builtin_fmaf(x, x, acc);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    return acc;
+}
+
+template <bool SCALAR>
+__device__ __forceinline__ void finish_rows(const WaveCtx& w, uint32_t m, uint32_t b0, float acc)
+{
+    const int cr = w.lane >> 2, cj = w.lane & 3;
+    float res = acc;
+    if (!SCALAR) {
+        // lane sums 0..3 of a row sit in 4 adjacent lanes: ((s0 + s1) + s2) + s3
+        const int q0 = w.lane & ~3;
+        const float a0 = __shfl(acc, q0), a1 = __shfl(acc, q0 + 1), a2 = __shfl(acc, q0 + 2), a3 = __shfl(acc, q0 + 3);
+        res = ((a0 + a1) + a2) + a3;
+    }
+    if (cj == 0 && b0 + cr < m) w.nb_dist[b0 + cr] = res;
+}
+
+// Distances from the query to the rows nb_id[0..m) -> nb_dist[0..m).  m <= 64, wave-uniform.
+// Rows of up to 128 used dims: the loads of 32 rows (a whole layer-0 list at M=16) are in
+// flight together before the first is consumed.  Wider rows go 16 rows x 128 dims at a time.
+template <bool SCALAR>
 __device__ __forceinline__ void compute_distances(const WaveCtx& w, uint32_t m)
 {
-    const int lane = w.lane;
-    const int h = lane >> 4, c = lane & 15;     // loader role: row h of a 4-row group, 16-byte chunk c of a segment
-    const int cr = lane >> 2, cj = lane & 3;    // chain role: row cr of the batch, lane-sum cj
-    for (uint32_t b0 = 0; b0 < m; b0 += 16) {
-        const float* rp[4];
-        bool ok[4];
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-            uint32_t r = b0 + 4 * g + h;
-            ok[g] = r < m;
-            uint32_t id = ok[g] ? w.nb_id[r] : 0u;
-            rp[g] = w.vectors + (size_t)id * w.row_stride + c * 4;
+    if (w.nseg <= 2) {
+        for (uint32_t b0 = 0; b0 < m; b0 += 32) {
+            RowRegs A, B;
+            DIAG_STAMP(d0);
+            load_rows(w, m, b0, 0, A);
+            const bool two = b0 + 16 < m;
+            if (two) load_rows(w, m, b0 + 16, 0, B);
+#ifdef HNSW_DIAG
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+            DIAG_STAMP(d1);
+            DIAG_ADD(w.cy_load, d0, d1);
+            float accA = chain_rows<SCALAR>(w, 0, A, 0.0f);
+            float accB = 0.0f;
+            if (two) accB = chain_rows<SCALAR>(w, 0, B, 0.0f);
+            DIAG_STAMP(d2);
+            DIAG_ADD(w.cy_chain, d1, d2);
+            finish_rows<SCALAR>(w, m, b0, accA);
+            if (two) finish_rows<SCALAR>(w, m, b0 + 16, accB);
+            DIAG_STAMP(d3);
+            DIAG_ADD(w.cy_fin, d2, d3);
         }
-        float acc = 0.0f;
-        for (uint32_t s0 = 0; s0 < w.nseg; s0 += 2) {
-            float4 reg[4][2];
-#pragma unroll
-            for (int s = 0; s < 2; s++) {
-                const uint32_t e0 = (s0 + s) * kSeg + c * 4;
-                const bool in = e0 < w.d_eff;
-#pragma unroll
-                for (int g = 0; g < 4; g++) {
-                    reg[g][s] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (ok[g] && in) reg[g][s] = *reinterpret_cast<const float4*>(rp[g] + (s0 + s) * kSeg);
-                }
+    } else {
+        for (uint32_t b0 = 0; b0 < m; b0 += 16) {
+            float acc = 0.0f;
+            for (uint32_t s0 = 0; s0 < w.nseg; s0 += 2) {
+                RowRegs A;
+                load_rows(w, m, b0, s0, A);
+                acc = chain_rows<SCALAR>(w, s0, A, acc);
             }
-#pragma unroll
-            for (int s = 0; s < 2; s++) {
-                if (s0 + s < w.nseg) {
-                    const uint32_t seg = s0 + s;
-                    const uint32_t e0 = seg * kSeg + c * 4;
-                    const float4 qv = *reinterpret_cast<const float4*>(w.qs + e0);
-#pragma unroll
-                    for (int g = 0; g < 4; g++) {
-                        float4 v = reg[g][s];
-                        float4 t;
-                        t.x = v.x - qv.x; t.y = v.y - qv.y; t.z = v.z - qv.z; t.w = v.w - qv.w;
-                        if (SCALAR && e0 < w.d4) { t.x = t.x * t.x; t.y = t.y * t.y; t.z = t.z * t.z; t.w = t.w * t.w; }
-                        *reinterpret_cast<float4*>(w.tile + (4 * g + h) * kTileStride + c * 4) = t;
-                    }
-                    __syncthreads();
-                    const uint32_t left = w.d_eff - seg * kSeg;          // dims of this segment
-                    if (!SCALAR) {
-                        const uint32_t steps = left >= kSeg ? 16u : (left >> 2);
-                        const float* tp = w.tile + cr * kTileStride + cj;
-                        if (steps == 16) {
-#pragma unroll
-                            for (int t = 0; t < 16; t++) { float x = tp[4 * t]; acc = __builtin_fmaf(x, x, acc); }
-                        } else {
-                            for (uint32_t t = 0; t < steps; t++) { float x = tp[4 * t]; acc = __builtin_fmaf(x, x, acc); }
-                        }
-                    } else if (cj == 0) {
-                        const uint32_t steps = left >= kSeg ? (uint32_t)kSeg : left;
-                        const float* tp = w.tile + cr * kTileStride;
-                        for (uint32_t t = 0; t < steps; t++) {
-                            float x = tp[t];
-                            if (seg * kSeg + t < w.d4) acc = acc + x; else acc = __builtin_fmaf(x, x, acc);
-                        }
-                    }
-                    __syncthreads();
-                }
-            }
+            finish_rows<SCALAR>(w, m, b0, acc);
         }
-        float res;
-        if (!SCALAR) {
-            const int q0 = lane & ~3;
-            float a0 = __shfl(acc, q0), a1 = __shfl(acc, q0 + 1), a2 = __shfl(acc, q0 + 2), a3 = __shfl(acc, q0 + 3);
-            res = ((a0 + a1) + a2) + a3;
-        } else {
-            res = acc;
-        }
-        if (cj == 0 && b0 + cr < m) w.nb_dist[b0 + cr] = res;
     }
     __syncthreads();
 }
 
-template <bool SCALAR>
+// WR = 0: the result list W is the libstdc++ max-heap in LDS, maintained exactly as the
+//         reference does (so even the choice among several equally distant worst entries
+//         is the reference's).
+// WR > 0: W is an unordered set, WR entries per lane in registers (ef <= 64*WR).  Only the
+//         largest distance f and the size of W steer the search, and both evolve
+//         identically; the one observable difference is which of several entries with
+//         exactly the worst distance is dropped.
+template <bool SCALAR, int WR>
 __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
 {
     extern __shared__ __align__(16) uint32_t smem[];
@@ -285,6 +450,10 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
 
     hnsw_amd_query_stats st = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t fail = 0;
+#ifdef HNSW_DIAG
+    uint32_t cy_pop = 0, cy_adj = 0, cy_dist = 0, cy_adm = 0, cy_up = 0, cy_fin = 0;
+#endif
+    DIAG_STAMP(t_begin);
 
     // ---- entry point of the top layer (src/hnsw.cpp:385-398) ----
     const int L = (int)a.g.nlayers - 1;
@@ -340,31 +509,48 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
         if (!fail) cur_slot = a.g.up_down[base + cur_slot];      // changeLayer, src/hnsw.h:575-587
     }
     st.n_visited_up = nvis;
+    DIAG_STAMP(t_up_end);
+    DIAG_ADD(cy_up, t_begin, t_up_end);
 
     // ---- layer 0 beam search (src/hnsw.cpp:413-415, 725-787) ----
     uint32_t nW = 0, nC = 0;
     float f = 0.0f;
+    uint32_t wd[WR > 0 ? WR : 1], wi[WR > 0 ? WR : 1];     // register form of W: distance bits, id
     if (!fail) {
         __syncthreads();
         for (uint32_t i = lane; i < H; i += 64) hash[i] = kEmpty;
         __syncthreads();
         if (lane == 0) {
-            W[0] = make_uint2(__float_as_uint(cur_dist), cur_id);
+            if (WR == 0) W[0] = make_uint2(__float_as_uint(cur_dist), cur_id);
             C[0] = make_uint2(float_keys ? __float_as_uint(cur_dist) : (uint32_t)trunc_key(cur_dist), cur_id);
             visited_insert(hash, hmask, hshift, cur_id);
         }
+#pragma unroll
+        for (int r = 0; r < (WR > 0 ? WR : 1); r++) { wd[r] = 0; wi[r] = 0; }
+        if (WR > 0 && lane == 0) { wd[0] = __float_as_uint(cur_dist); wi[0] = cur_id; }
         nW = 1; nC = 1; nvis = 1; f = cur_dist; st.max_c = 1;
         __syncthreads();
         while (nC > 0) {
-            uint32_t ckey = 0, cid = 0;
-            if (lane == 0) { uint2 c = C[0]; ckey = c.x; cid = c.y; c_pop(C, nC); }
-            nC--;
-            ckey = rfl(ckey); cid = rfl(cid);
+            DIAG_STAMP(t0);
+            uint32_t ckey, cid;
+            uint32_t my = kEmpty;
+            {
+                const uint2 c = C[0];
+                ckey = rfl(c.x); cid = rfl(c.y);
+                // the candidate's neighbour list is requested now and arrives while the heap is repaired
+                if ((uint32_t)lane < a.g.deg0) my = a.g.adj0[(size_t)cid * a.g.deg0 + lane];
+                if (nC > 1) {
+                    if (nC <= kWaveHeapMax) heap_pop_wave<COrder>(C, nC, lane);
+                    else if (lane == 0) c_pop(C, nC);
+                }
+                nC--;
+                __syncthreads();
+            }
+            DIAG_STAMP(t1);
+            DIAG_ADD(cy_pop, t0, t1);
             if (float_keys) { if (__uint_as_float(ckey) > f) break; }
             else { if ((float)(int32_t)ckey > f) break; }
             if (nvis + 64 > visit_limit) { fail = 1; break; }
-            uint32_t my = kEmpty;
-            if ((uint32_t)lane < a.g.deg0) my = a.g.adj0[(size_t)cid * a.g.deg0 + lane];
             const bool live = my != kEmpty;
             const bool fresh = live && visited_insert(hash, hmask, hshift, my);
             const unsigned long long fm = __ballot(fresh);
@@ -374,38 +560,88 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
             st.n_expand++; st.sum_deg0 += (uint32_t)__popcll(__ballot(live));
             st.n_dist += m; nvis += m;
             __syncthreads();
+            DIAG_STAMP(t2);
+            DIAG_ADD(cy_adj, t1, t2);
             if (m == 0) continue;
             compute_distances<SCALAR>(w, m);
+            DIAG_STAMP(t3);
+            DIAG_ADD(cy_dist, t2, t3);
             // Admission in list order (src/hnsw.cpp:765-777).  A neighbour that fails
             // `dist < f` against the f at the start of the expansion can only be admitted
             // while W is not full; f never grows once W is full, so skipping the others is exact.
             const float dj = (uint32_t)lane < m ? w.nb_dist[lane] : 0.0f;
+            const uint32_t idj = (uint32_t)lane < m ? w.nb_id[lane] : 0u;
             unsigned long long todo = __ballot((uint32_t)lane < m && (dj < f || nW < ef));
             if (nC + (uint32_t)__popcll(todo) > a.cap_c) { fail = 2; break; }
-            if (lane == 0) {
-                while (todo) {
-                    const int j = __builtin_ctzll(todo);
-                    todo &= todo - 1;
-                    const float dist = w.nb_dist[j];
-                    if (dist < f || nW < ef) {
-                        const uint32_t id = w.nb_id[j];
-                        C[nC] = make_uint2(float_keys ? __float_as_uint(dist) : (uint32_t)trunc_key(dist), id);
-                        nC++;
-                        c_push(C, nC);
-                        if (nC > st.max_c) st.max_c = nC;
-                        W[nW] = make_uint2(__float_as_uint(dist), id);
-                        nW++;
-                        w_push(W, nW);
-                        if (nW > ef) { w_pop(W, nW); nW--; }
+            while (todo) {
+                const int j = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                const float dist = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(dj), j));
+                if (dist < f || nW < ef) {
+                    const uint32_t id = __builtin_amdgcn_readlane(idj, j);
+                    const uint2 ce = make_uint2(float_keys ? __float_as_uint(dist) : (uint32_t)trunc_key(dist), id);
+                    const uint2 we = make_uint2(__float_as_uint(dist), id);
+                    nC++;
+                    if (WR > 0) {
+                        if (nC <= kWaveHeapMax) heap_push_wave<COrder>(C, nC, ce, lane);
+                        else { if (lane == 0) { C[nC - 1] = ce; c_push(C, nC); } }
+                        if (nW < ef) {
+                            // W not full: append; f stays the largest distance in W
+#pragma unroll
+                            for (int r = 0; r < WR; r++)
+                                if ((nW >> 6) == (uint32_t)r && (nW & 63u) == (uint32_t)lane) { wd[r] = we.x; wi[r] = we.y; }
+                            nW++;
+                            f = dist > f ? dist : f;
+                        } else {
+                            // W full and dist < f: the new entry replaces one entry at distance f
+                            const uint32_t fb = __float_as_uint(f);
+                            bool done = false;
+                            uint32_t mx = 0;
+#pragma unroll
+                            for (int r = 0; r < WR; r++) {
+                                const unsigned long long hit = done ? 0ull : __ballot(wd[r] == fb);
+                                if (hit) { if (lane == __builtin_ctzll(hit)) { wd[r] = we.x; wi[r] = we.y; } done = true; }
+                                mx = wd[r] > mx ? wd[r] : mx;
+                            }
+                            f = __uint_as_float(wave_max_u32(mx));   // non-negative floats order as their bit patterns
+                        }
+                        __syncthreads();
+                    } else {
+                    nW++;
+                    if (nC <= kWaveHeapMax && nW <= kWaveHeapMax) {
+                        heap_push_wave<COrder>(C, nC, ce, lane);
+                        heap_push_wave<WOrder>(W, nW, we, lane);
+                        __syncthreads();
+                        if (nW > ef) {
+                            const uint2 root = heap_pop_wave<WOrder>(W, nW, lane);
+                            nW--;
+                            f = __uint_as_float(root.x);
+                            __syncthreads();
+                        } else {
+                            f = __uint_as_float(W[0].x);
+                        }
+                    } else {
+                        if (lane == 0) {
+                            C[nC - 1] = ce; c_push(C, nC);
+                            W[nW - 1] = we; w_push(W, nW);
+                            if (nW > ef) w_pop(W, nW);
+                        }
+                        if (nW > ef) nW--;
+                        __syncthreads();
                         f = __uint_as_float(W[0].x);
                     }
+                    }
+                    if (nC > st.max_c) st.max_c = nC;
                 }
             }
             nW = rfl(nW); nC = rfl(nC); f = rflf(f); st.max_c = rfl(st.max_c);
             __syncthreads();
+            DIAG_STAMP(t4);
+            DIAG_ADD(cy_adm, t3, t4);
         }
     }
     st.n_visited0 = nvis;
+    DIAG_STAMP(t_l0_end);
 
     if (fail) {
         if (lane == 0) {
@@ -418,6 +654,12 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
 
     // ---- sort W ascending by (distance, id) (src/hnsw.cpp:447) and write the first out_k ----
     __syncthreads();
+    if (WR > 0) {
+#pragma unroll
+        for (int r = 0; r < WR; r++)
+            if ((uint32_t)(r * 64 + lane) < nW) W[r * 64 + lane] = make_uint2(wd[r], wi[r]);
+        __syncthreads();
+    }
     for (uint32_t i = lane; i < nW; i += 64) {
         const uint2 me = W[i];
         uint32_t rank = 0;
@@ -434,6 +676,17 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
         a.out_ids[(size_t)qi * a.out_k + i] = kEmpty;
         a.out_dist[(size_t)qi * a.out_k + i] = __builtin_inff();
     }
+#ifdef HNSW_DIAG
+    {
+        DIAG_STAMP(t_end);
+        DIAG_ADD(cy_fin, t_l0_end, t_end);
+        st.max_c = st.n_expand;
+        st.n_dist = cy_pop; st.n_expand = cy_adj; st.n_sweeps = cy_dist; st.sum_deg0 = cy_adm;
+        st.sum_degu = cy_up; st.n_visited0 = cy_fin; st.n_visited_up = (uint32_t)(t_end - t_begin);
+        // finer split of the distance phase, in place of two of the coarse sums
+        st.n_dist = w.cy_load; st.sum_degu = w.cy_chain; st.n_visited0 = w.cy_fin;
+    }
+#endif
     if (lane == 0) {
         if (a.out_count) a.out_count[qi] = nW;
         if (a.stats) a.stats[qi] = st;
@@ -517,7 +770,7 @@ static ScratchTier tier_for(int ef, int tier)
     uint32_t want_visit = (uint32_t)ef * 28u + 256u;
     uint32_t bits = 10;
     while ((1u << bits) - (1u << (bits - 3)) < want_visit + 64) bits++;
-    uint32_t cap_c = ((uint32_t)ef * 6u + 127u) & ~63u;
+    uint32_t cap_c = ((uint32_t)ef * 4u + 127u) & ~63u;
     bits += (uint32_t)tier;
     cap_c <<= tier;
     return ScratchTier{bits, cap_c};
@@ -564,7 +817,10 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
         }
         a.fail_count = cur; a.fail_list = cur + 1;
         HIP_CHECK(hipMemsetAsync(cur, 0, 4, stream));
-        auto kern = scalar ? hnsw_search_kernel<true> : hnsw_search_kernel<false>;
+        void (*kern)(SearchArgs);
+        const bool std_heap = (flags & HNSW_AMD_W_STD_HEAP) != 0 || ef > 256;
+        if (scalar) kern = std_heap ? hnsw_search_kernel<true, 0> : (ef <= 64 ? hnsw_search_kernel<true, 1> : (ef <= 128 ? hnsw_search_kernel<true, 2> : hnsw_search_kernel<true, 4>));
+        else kern = std_heap ? hnsw_search_kernel<false, 0> : (ef <= 64 ? hnsw_search_kernel<false, 1> : (ef <= 128 ? hnsw_search_kernel<false, 2> : hnsw_search_kernel<false, 4>));
         if (lds > 32768)
             HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3(a.nq_launch), dim3(64), lds, stream, a);

@@ -45,7 +45,12 @@ enum {
                                      (src/hnsw.h:387-400) */
     HNSW_AMD_KEYS_INT32 = 0,      /* candidate heap keyed by int32-truncated distances, as the reference
                                      (src/hnsw.cpp:727,767) */
-    HNSW_AMD_KEYS_FLOAT = 2       /* candidate heap keyed by the float distance (textbook HNSW; not the reference) */
+    HNSW_AMD_KEYS_FLOAT = 2,      /* candidate heap keyed by the float distance (textbook HNSW; not the reference) */
+    HNSW_AMD_W_STD_HEAP = 4       /* keep the result list W_ as the libstdc++ binary heap the reference keeps
+                                     (src/hnsw.cpp:770-775), so that when several entries tie for the worst
+                                     distance the one dropped is the reference's choice as well.  Default (flag
+                                     clear): W_ is an unordered register set, faster; same distances, same ids
+                                     except possibly among entries exactly tied with the worst kept distance. */
 };
 
 /* Per-query counters, identical between this library and the CPU restatement used to

@@ -19,27 +19,32 @@ def _flags(g):
 
 
 @pytest.mark.parametrize("name", golden_names())
-def test_kernel_matches_reference_W(name):
+@pytest.mark.parametrize("w", ["set", "std_heap"])
+def test_kernel_matches_reference_W(name, w):
     g = Golden(name)
     h = HNSW(*g.meta["ctor"])
     h.import_flat(g.graph, g.base)
-    h.flags = _flags(g)
+    h.flags = _flags(g) | (capi.W_STD_HEAP if w == "std_heap" else 0)
     for ef, (ids_ref, dist_ref, cnt_ref) in g.results.items():
         ids, dist, cnt = h.search_batch(g.queries, ef)
         assert np.array_equal(cnt, cnt_ref), f"{name} ef={ef}: |W_| differs"
         assert_same_results(ids, dist, ids_ref, dist_ref, what=f"{name} ef={ef}")
+        if w == "std_heap":
+            # W_ kept as the reference keeps it: even the members of the last tie group agree
+            assert np.array_equal(np.sort(ids, axis=1), np.sort(ids_ref, axis=1))
 
 
 @pytest.mark.parametrize("name", ["int_d32_n2000", "unit_d100_n2000_sse", "unit_d100_n2000_scalar", "int_d16_n1000_m5"])
 @pytest.mark.parametrize("keys", ["int32", "float"])
-def test_kernel_matches_oracle_with_counters(name, keys):
+@pytest.mark.parametrize("w", ["set", "std_heap"])
+def test_kernel_matches_oracle_with_counters(name, keys, w):
     g = Golden(name)
     h = HNSW(*g.meta["ctor"])
     h.import_flat(g.graph, g.base)
     kflag, kmode = (capi.KEYS_FLOAT, oracle.KEYS_FLOAT) if keys == "float" else (capi.KEYS_INT32, oracle.KEYS_INT32)
-    dflag = capi.DIST_SCALAR if g.dist_mode == 1 else capi.DIST_SSE
+    dflag = (capi.DIST_SCALAR if g.dist_mode == 1 else capi.DIST_SSE) | (capi.W_STD_HEAP if w == "std_heap" else 0)
     idx = oracle.OracleIndex(g.graph, g.base)
-    for ef in (1, 7, 33, 128):
+    for ef in (1, 7, 33, 64, 65, 128, 129, 300):
         ids, dist, cnt, st = h.search_batch(g.queries, ef, flags=dflag | kflag, stats=True)
         oi, od, oc, ost = idx.search(g.queries, ef, dist_mode=g.dist_mode, key_mode=kmode, stats=True)
         assert np.array_equal(cnt, oc)
@@ -63,6 +68,7 @@ def test_aproximateKnn_fills_W_like_the_reference():
     h = HNSW(*g.meta["ctor"])
     h.import_flat(g.graph, g.base)
     ids_ref, dist_ref, cnt_ref = g.results[10]
+    h.flags |= capi.W_STD_HEAP
     for i in range(5):
         h.aproximateKnn(g.queries[i], 10, 10)
         assert len(h.W_) == cnt_ref[i]

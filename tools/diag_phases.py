@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Where a query's cycles go (diagnostic build only).
+
+    make -C hnsw_amd/csrc diag
+    HNSW_AMD_LIB=hnsw_amd/libhnsw_amd_diag.so python tools/diag_phases.py --n 1000000 --ef 50
+
+The diagnostic library overwrites the per-query counters with s_memtime cycle sums per phase
+of the layer-0 loop; the shipped library contains no stamps."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hnsw_amd import HNSW, datagen  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--n", type=int, default=1_000_000)
+ap.add_argument("--nq", type=int, default=10_000)
+ap.add_argument("--ef", type=int, default=50)
+ap.add_argument("--threads", type=int, default=16)
+a = ap.parse_args()
+base = datagen.make("sift", a.n, seed=1)
+q = datagen.make("sift", a.nq, seed=1, stream=1)
+h = HNSW(16, 16, 200)
+h.init(128, a.n)
+t = time.time(); h.insert_batch(base, threads=a.threads); print(f"build {time.time()-t:.1f}s", flush=True)
+h.sync_device(0)
+for rep in range(2):
+    t = time.time()
+    ids, ds, cnt, st = h.search_batch(q, a.ef, out_k=10, stats=True)
+    dt = time.time() - t
+names = [("n_expand", "adjacency+visited"), ("n_sweeps", "gather+distance"), ("n_dist", "  dist: load+wait"),
+         ("sum_degu", "  dist: tile+chain"), ("n_visited0", "  dist: combine"), ("sum_deg0", "admission"), ("n_visited_up", "TOTAL")]
+tot = st["n_visited_up"].astype(np.float64).mean()
+print(f"host wall {dt*1e3:.2f} ms for {a.nq} queries; expansions/query {st['max_c'].mean():.1f}")
+for f, label in names:
+    v = st[f].astype(np.float64).mean()
+    print(f"{label:22s} {v:12.0f} cycles/query  {100*v/tot:5.1f}%   per expansion {v/st['max_c'].mean():8.0f}")

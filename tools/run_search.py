@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Minimal driver for profiling: build (or load) an index and run the batched search a few
+times, nothing else on the GPU (no torch).  Usage: run_search.py [--n N] [--ef EF] [--reps R]"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hnsw_amd import HNSW, datagen  # noqa: E402
+from hnsw_amd.flatgraph import FlatGraph  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--n", type=int, default=1_000_000)
+ap.add_argument("--nq", type=int, default=10_000)
+ap.add_argument("--ef", type=int, default=50)
+ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--threads", type=int, default=16)
+ap.add_argument("--cache", default="")
+a = ap.parse_args()
+base = datagen.make("sift", a.n, seed=1)
+q = datagen.make("sift", a.nq, seed=1, stream=1)
+h = HNSW(16, 16, 200)
+if a.cache and os.path.exists(a.cache):
+    h.import_flat(FlatGraph.from_npz(np.load(a.cache)), base)
+else:
+    h.init(128, a.n)
+    t = time.time(); h.insert_batch(base, threads=a.threads); print(f"build {time.time()-t:.1f}s", flush=True)
+    if a.cache:
+        np.savez(a.cache, **h.export_flat().to_npz_dict())
+h.sync_device(0)
+for rep in range(a.reps):
+    t = time.time()
+    ids, ds, cnt, st = h.search_batch(q, a.ef, out_k=10, stats=True)
+    print(f"rep {rep}: host wall {1e3*(time.time()-t):.2f} ms", flush=True)
+print("n_dist/q", st["n_dist"].mean(), "expansions/q", st["n_expand"].mean())
