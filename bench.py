@@ -62,10 +62,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the search has no CPU path)")
+    # one GPU per rank; HNSW_AMD_BENCH_BACKEND=gloo lets several ranks share a GPU (rehearsal on a 1-GPU box)
+    backend = os.environ.get("HNSW_AMD_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     d = datagen.KINDS[args.kind]
     k = args.k
@@ -105,29 +111,27 @@ def main():
     cnt_t = torch.empty((nq,), dtype=torch.int32, device=dev)
     stats_t = torch.empty((nq, 8), dtype=torch.int32, device=dev)
     flags = capi.DIST_SSE | (capi.KEYS_FLOAT if args.keys == "float" else capi.KEYS_INT32)
+    h.flags = flags
     offsets = np.array([r * args.n // world for r in range(world)], dtype=np.uint32)
-    if world > 1:
-        g_dist = torch.empty((world, nq, k), dtype=torch.float32, device=dev)
-        g_ids = torch.empty((world, nq, k), dtype=torch.int32, device=dev)
     out_ids = torch.empty((nq, k), dtype=torch.int32, device=dev)
     out_dist = torch.empty((nq, k), dtype=torch.float32, device=dev)
     L = capi.lib()
 
+    from hnsw_amd.sharded import ShardedHNSW
+    sh = ShardedHNSW.__new__(ShardedHNSW)      # wrap the index built above
+    sh.n_total, sh.d, sh.rank, sh.world, sh.lo, sh.hi = args.n, d, rank, world, lo, hi
+    sh.offsets, sh.group, sh.index = offsets, None, h
+
     def step(ef, out_k, want_stats=False):
         """One pass over the query batch; leaves the final top-out_k (global ids) in out_ids/out_dist."""
         stream = torch.cuda.current_stream().cuda_stream
-        if world == 1:
+        if world == 1 or want_stats:
             h.search_batch_device(q_t.data_ptr(), nq, ef, out_k, out_ids.data_ptr(), out_dist.data_ptr(), cnt_t.data_ptr(),
                                   stats_t.data_ptr() if want_stats else 0, stream, flags)
-            return
-        h.search_batch_device(q_t.data_ptr(), nq, ef, out_k, ids_t.data_ptr(), dist_t.data_ptr(), cnt_t.data_ptr(),
-                              stats_t.data_ptr() if want_stats else 0, stream, flags)
-        loc_d = dist_t.view(-1)[: nq * out_k].view(nq, out_k)
-        loc_i = ids_t.view(-1)[: nq * out_k].view(nq, out_k)
-        dist.all_gather_into_tensor(g_dist.view(-1), loc_d.reshape(-1))
-        dist.all_gather_into_tensor(g_ids.view(-1), loc_i.reshape(-1))
-        capi.check(L.hnsw_amd_merge_topk_device(g_dist.data_ptr(), g_ids.data_ptr(), capi.u32(offsets), world, nq, out_k, out_k,
-                                                out_ids.data_ptr(), out_dist.data_ptr(), stream))
+            if world == 1:
+                return
+        i_t, d_t = sh.search(q_t, ef, out_k)
+        out_ids.copy_(i_t); out_dist.copy_(d_t)
 
     # ---- exact ground truth (brute force on the GPU over every shard, merged) ----
     t0 = time.time()

@@ -16,6 +16,8 @@
 using namespace hnsw_amd;
 
 namespace hnsw_amd {
+void hdf_get_dimensions(const char* filename, const char* dataset, uint64_t dims[2]);
+void hdf_read(const char* filename, const char* dataset, void* data, bool as_float);
 void merge_topk(const float* d_dist, const uint32_t* d_ids, const uint32_t* shard_offset, uint32_t S, uint32_t nq, uint32_t k,
                 uint32_t out_k, uint32_t* d_out_ids, float* d_out_dist, void* stream);
 }
@@ -217,6 +219,21 @@ int hnsw_amd_export_flat(hnsw_amd_index* h, hnsw_amd_flat_graph* g, const float*
         g->up_adj_order = f.up_adj_order.data(); g->ep_slot = f.ep_slot.data(); g->ep_order = f.ep_order.data();
         if (vectors) *vectors = h->host.vector_data_.data();
     });
+}
+
+int hnsw_amd_hdf_get_dimensions(const char* filename, const char* dataset, uint64_t dims[2])
+{
+    return guarded([&] { REQUIRE(filename && dataset && dims, "hdf_get_dimensions: NULL argument"); hdf_get_dimensions(filename, dataset, dims); });
+}
+
+int hnsw_amd_hdf_read_float(const char* filename, const char* dataset, float* data)
+{
+    return guarded([&] { REQUIRE(filename && dataset && data, "hdf_read_float: NULL argument"); hdf_read(filename, dataset, data, true); });
+}
+
+int hnsw_amd_hdf_read_int(const char* filename, const char* dataset, int* data)
+{
+    return guarded([&] { REQUIRE(filename && dataset && data, "hdf_read_int: NULL argument"); hdf_read(filename, dataset, data, false); });
 }
 
 int hnsw_amd_merge_topk_device(const float* d_dist, const uint32_t* d_ids, const uint32_t* shard_offset, uint32_t n_shards,

@@ -1,0 +1,95 @@
+"""Sharded multi-GPU search: one process per GPU, each holding an independently built
+sub-graph over a contiguous slice of the base set; queries are replicated, every rank
+searches its shard, the per-shard top-k lists are all-gathered (RCCL over xGMI when the
+process group's backend is "nccl") and merged on the device.
+
+The reference is a single in-memory index (no counterpart); this is the layout the
+multi-GPU configurations of the benchmark use.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import capi
+from .index import HNSW
+
+
+def shard_range(n_total: int, rank: int, world: int) -> tuple[int, int]:
+    """Rows [lo, hi) of the base set owned by `rank`: contiguous, sizes differ by at most one."""
+    if not (0 <= rank < world):
+        raise ValueError("rank out of range")
+    return rank * n_total // world, (rank + 1) * n_total // world
+
+
+def shard_offsets(n_total: int, world: int) -> np.ndarray:
+    return np.array([shard_range(n_total, r, world)[0] for r in range(world)], dtype=np.uint32)
+
+
+def merge_topk_numpy(dist: np.ndarray, ids: np.ndarray, offsets: np.ndarray, out_k: int):
+    """Host statement of the merge the device kernel performs: dist/ids are [S, nq, k] with
+    shard-local ids (0xFFFFFFFF = padding); returns the out_k nearest per query as global
+    ids, ascending distance, ties by id."""
+    S, nq, k = dist.shape
+    gid = ids.astype(np.int64) + offsets.astype(np.int64)[:, None, None]
+    pad = ids == np.uint32(0xFFFFFFFF)
+    gid[pad] = 0xFFFFFFFF
+    d = np.where(pad, np.inf, dist).transpose(1, 0, 2).reshape(nq, S * k)
+    g = gid.transpose(1, 0, 2).reshape(nq, S * k)
+    order = np.lexsort((g, d), axis=1)[:, :out_k]
+    od = np.take_along_axis(d, order, 1).astype(np.float32)
+    og = np.take_along_axis(g, order, 1).astype(np.uint32)
+    if od.shape[1] < out_k:
+        padn = out_k - od.shape[1]
+        od = np.concatenate([od, np.full((nq, padn), np.inf, np.float32)], 1)
+        og = np.concatenate([og, np.full((nq, padn), 0xFFFFFFFF, np.uint32)], 1)
+    return og, od
+
+
+class ShardedHNSW:
+    """The rank-local part of a sharded index plus the exchange step.
+
+    search(q, ef, k) is collective: every rank of `group` must call it with the same
+    queries.  `local_search` and `merge` can be replaced (CPU tests run the exchange
+    over gloo with host tensors and a host merge); by default they are the GPU kernels.
+    """
+
+    def __init__(self, n_total: int, d: int, rank: int, world: int, ctor=(16, 16, 200), device: int = 0, group=None):
+        self.n_total, self.d, self.rank, self.world = n_total, d, rank, world
+        self.lo, self.hi = shard_range(n_total, rank, world)
+        self.offsets = shard_offsets(n_total, world)
+        self.group = group
+        self.index = HNSW(*ctor, device=device)
+
+    def build(self, shard_rows: np.ndarray, threads: int = 1) -> None:
+        if shard_rows.shape != (self.hi - self.lo, self.d):
+            raise ValueError(f"rank {self.rank} owns rows [{self.lo}, {self.hi}): got {shard_rows.shape}")
+        self.index.init(self.d, self.hi - self.lo)
+        self.index.insert_batch(shard_rows, threads=threads)
+
+    def search(self, q_t, ef: int, k: int, *, local_search=None, merge=None):
+        """q_t: torch tensor [nq, d] float32 (on this rank's GPU, or on the CPU when the hooks
+        are given).  Returns (ids [nq,k] int32 holding global ids, dist [nq,k] float32)."""
+        import torch
+        import torch.distributed as dist
+
+        nq = q_t.shape[0]
+        if local_search is None:
+            loc_i = torch.empty((nq, k), dtype=torch.int32, device=q_t.device)
+            loc_d = torch.empty((nq, k), dtype=torch.float32, device=q_t.device)
+            self.index.search_batch_device(q_t.data_ptr(), nq, ef, k, loc_i.data_ptr(), loc_d.data_ptr(), 0, 0,
+                                           torch.cuda.current_stream().cuda_stream)
+        else:
+            loc_i, loc_d = local_search(q_t, ef, k)
+        if self.world == 1:
+            return loc_i, loc_d
+        g_i = torch.empty((self.world, nq, k), dtype=torch.int32, device=q_t.device)
+        g_d = torch.empty((self.world, nq, k), dtype=torch.float32, device=q_t.device)
+        dist.all_gather_into_tensor(g_i.view(-1), loc_i.reshape(-1), group=self.group)
+        dist.all_gather_into_tensor(g_d.view(-1), loc_d.reshape(-1), group=self.group)
+        if merge is not None:
+            return merge(g_d, g_i, self.offsets, k)
+        out_i = torch.empty((nq, k), dtype=torch.int32, device=q_t.device)
+        out_d = torch.empty((nq, k), dtype=torch.float32, device=q_t.device)
+        capi.check(capi.lib().hnsw_amd_merge_topk_device(g_d.data_ptr(), g_i.data_ptr(), capi.u32(self.offsets), self.world, nq, k, k,
+                                                         out_i.data_ptr(), out_d.data_ptr(), torch.cuda.current_stream().cuda_stream))
+        return out_i, out_d

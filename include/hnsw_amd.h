@@ -135,6 +135,15 @@ int hnsw_amd_export_flat(hnsw_amd_index* h, hnsw_amd_flat_graph* g, const float*
  * themselves when the index changed; calling it first keeps the upload out of timings. */
 int hnsw_amd_sync_device(hnsw_amd_index* h, int device);
 
+/* HDF5 input path.  hdfReader::getDimensions — src/hdfReader.cpp:9-23 (dims of a 2-D
+ * dataset; a 1-D dataset reports dims[1] = 1); hdfReader::readData(float*) — :26-42 and
+ * readData(int*) — :45-61 (the whole dataset, converted to float / int, into a buffer the
+ * caller sized from the dimensions).  libhdf5 is loaded at run time; without it these
+ * return HNSW_AMD_E_IO and everything else still works. */
+int hnsw_amd_hdf_get_dimensions(const char* filename, const char* dataset, uint64_t dims[2]);
+int hnsw_amd_hdf_read_float(const char* filename, const char* dataset, float* data);
+int hnsw_amd_hdf_read_int(const char* filename, const char* dataset, int* data);
+
 /* Sharded multi-GPU search, combine step (no counterpart in the reference, which is one
  * in-memory index): d_dist / d_ids hold n_shards per-shard result blocks of nq x k each
  * (ids local to the shard, 0xFFFFFFFF = padding), as an all-gather leaves them;
