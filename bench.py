@@ -38,8 +38,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=1_000_000, help="base vectors (whole job)")
-    ap.add_argument("--nq", type=int, default=10_000)
+    ap.add_argument("--base-size", dest="n", type=int, default=1_000_000, help="base vectors (whole job)")
+    ap.add_argument("--queries", dest="nq", type=int, default=10_000)
     ap.add_argument("--kind", default="sift")
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--ef", type=int, default=0, help="0 = smallest ef of the reference sweep with recall@10 >= target")
@@ -184,6 +184,7 @@ def main():
     recall = harness.recall_at_k(ids_final, gt, k)
 
     # ---- timed region ----
+    log(f"rank {rank}: operating point ef={ef} recall@10={recall:.4f}; timing {args.steps} steps")
     for _ in range(args.warmup):
         step(ef, k)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -208,6 +209,7 @@ def main():
         elapsed = float(tt.item())
     ms_per_step = elapsed / args.steps * 1e3
     qps = nq * args.steps / elapsed
+    log(f"rank {rank}: {ms_per_step:.3f} ms/step")
 
     # search-kernel time alone (events around the search call only; N=1: the whole step)
     if world == 1:
