@@ -224,6 +224,15 @@ def main():
         torch.cuda.synchronize()
         kern_ms = float(np.mean([a.elapsed_time(b) for a, b in kev]))
     achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
+    # HBM bytes per launch from the PMC passes of tools/pmc_passes.sh over this same workload
+    # (FETCH_SIZE doubled as the gfx950 counter requires, plus WRITE_SIZE); a profile of
+    # another workload does not apply
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_search_kernel_latest.json")
+    if world == 1 and os.path.exists(tpath) and args.n == 1_000_000 and nq == 10_000 and args.kind == "sift" and ef == 50:
+        with open(tpath) as f:
+            pm = json.load(f)
+        traffic = pm.get("hbm_read_bytes_x2", 0) + pm.get("hbm_write_bytes", 0) or None
 
     # ---- CPU baseline on the host cores (rank 0, N=1 only): bounded sample, the reference's protocol ----
     cpu = None
@@ -270,7 +279,7 @@ def main():
                        "ef": ef, "recall_at_10": round(recall, 4), "reference_precision_top11": prec_ref,
                        "ef_sweep": sweep, "build_s": round(build_s, 1), "build_threads": args.build_threads},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": "hnsw_search_kernel", "kernel_ms": round(kern_ms, 4),
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "bytes_per_query": round(bytes_per_launch / nq, 1)},

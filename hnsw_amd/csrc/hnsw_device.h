@@ -45,7 +45,7 @@ struct SearchArgs {
     uint32_t* fail_list;      // their query indices
 };
 
-size_t search_lds_bytes(const SearchArgs& a);
+size_t search_lds_bytes(const SearchArgs& a, bool w_in_lds);
 
 class DeviceIndex {
 public:

@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -48,6 +49,11 @@ __device__ __forceinline__ int32_t trunc_key(float f)
     if (!(f >= -2147483648.0f && f < 2147483648.0f)) return (int32_t)0x80000000;
     return (int32_t)f;
 }
+
+// The workgroup is one wavefront, and a wavefront's LDS instructions execute in program
+// order, so data one lane wrote is visible to any lane's later read without a barrier or a
+// wait: only the compiler has to be kept from reordering the accesses.
+#define LDS_SYNC() asm volatile("" ::: "memory")
 
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ float rflf(float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); }
@@ -194,25 +200,24 @@ __device__ __forceinline__ uint2 heap_pop_wave(uint2* a, uint32_t n /* size befo
     const uint32_t len = n - 1;
     const uint2 v = a[len];
     const uint32_t nint = (len - 1) >> 1;      // nodes with both children inside [0, len)
-    unsigned long long m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+    // lane i (+64, +128, +192): the child node i hands the hole to
+    uint32_t nx0 = 0, nx1 = 0, nx2 = 0, nx3 = 0;
     {
-        bool l0 = false, l1 = false, l2 = false, l3 = false;
         uint32_t i = lane;
-        if (i < nint) l0 = Ord::before(a[2 * i + 2], a[2 * i + 1]);
-        if (nint > 64)  { i = lane + 64;  if (i < nint) l1 = Ord::before(a[2 * i + 2], a[2 * i + 1]); }
-        if (nint > 128) { i = lane + 128; if (i < nint) l2 = Ord::before(a[2 * i + 2], a[2 * i + 1]); }
-        if (nint > 192) { i = lane + 192; if (i < nint) l3 = Ord::before(a[2 * i + 2], a[2 * i + 1]); }
-        m0 = __ballot(l0);
-        if (nint > 64) m1 = __ballot(l1);
-        if (nint > 128) m2 = __ballot(l2);
-        if (nint > 192) m3 = __ballot(l3);
+        if (i < nint) nx0 = 2 * i + 2 - (Ord::before(a[2 * i + 2], a[2 * i + 1]) ? 1u : 0u);
+        if (nint > 64)  { i = lane + 64;  if (i < nint) nx1 = 2 * i + 2 - (Ord::before(a[2 * i + 2], a[2 * i + 1]) ? 1u : 0u); }
+        if (nint > 128) { i = lane + 128; if (i < nint) nx2 = 2 * i + 2 - (Ord::before(a[2 * i + 2], a[2 * i + 1]) ? 1u : 0u); }
+        if (nint > 192) { i = lane + 192; if (i < nint) nx3 = 2 * i + 2 - (Ord::before(a[2 * i + 2], a[2 * i + 1]) ? 1u : 0u); }
     }
+    // walk the hole down; lane k records step k of the path (from -> to)
     uint32_t cur = 0, d = 0, my_from = 0, my_to = 0;
     while (cur < nint) {
-        const uint32_t w = cur >> 6;
-        const unsigned long long mm = w == 0 ? m0 : (w == 1 ? m1 : (w == 2 ? m2 : m3));
-        const uint32_t takes_left = (uint32_t)(mm >> (cur & 63)) & 1u;
-        const uint32_t nxt = 2 * cur + 2 - takes_left;
+        const uint32_t w = cur >> 6, l = cur & 63;
+        uint32_t nxt;
+        if (w == 0) nxt = __builtin_amdgcn_readlane(nx0, l);
+        else if (w == 1) nxt = __builtin_amdgcn_readlane(nx1, l);
+        else if (w == 2) nxt = __builtin_amdgcn_readlane(nx2, l);
+        else nxt = __builtin_amdgcn_readlane(nx3, l);
         if ((uint32_t)lane == d) { my_from = nxt; my_to = cur; }
         cur = nxt; d++;
     }
@@ -269,6 +274,7 @@ struct WaveCtx {
     uint32_t* nb_slot;    // 64
     const float* vectors;
     uint32_t row_stride;
+    uint32_t table_bytes; // size of the vector table if it is below 4 GiB (32-bit offsets), else 0
     uint32_t d_eff;       // dims the distance uses
     uint32_t nseg;        // ceil(d_eff / 64)
     uint32_t d4;          // scalar mode: dims whose square is rounded before the add
@@ -286,6 +292,29 @@ struct RowRegs { float4 r[4][2]; };    // one lane's share of 16 rows x 2 segmen
 __device__ __forceinline__ void load_rows(const WaveCtx& w, uint32_t m, uint32_t b0, uint32_t s0, RowRegs& R)
 {
     const int h = w.lane >> 4, c = w.lane & 15;
+    if (w.table_bytes != 0) {
+        // The whole table is addressable with a 32-bit byte offset: buffer loads.  A lane with
+        // nothing to fetch (row index past m, chunk past the used dims) gets an offset beyond
+        // the table; the hardware range check returns zeros for it without touching memory,
+        // so there is no branching around the loads.
+        typedef unsigned u4v __attribute__((ext_vector_type(4)));
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(w.vectors), 0, (int)w.table_bytes, 0x00020000);
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const uint32_t r = b0 + 4 * g + h;
+            const uint32_t id = w.nb_id[r & 63u];
+            const uint32_t row_off = id * (w.row_stride * 4u) + (uint32_t)c * 16u;
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                const uint32_t e0 = (s0 + s) * kSeg + c * 4;
+                const uint32_t off = (r < m && e0 < w.d_eff) ? row_off + (s0 + s) * (kSeg * 4u) : 0xFFFFFFFFu;
+                const u4v v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off, 0, 0);
+                R.r[g][s] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int g = 0; g < 4; g++) {
         const uint32_t r = b0 + 4 * g + h;
@@ -326,7 +355,7 @@ __device__ __forceinline__ float chain_rows(const WaveCtx& w, uint32_t s0, const
                 if (SCALAR && e0 < w.d4) { t.x = t.x * t.x; t.y = t.y * t.y; t.z = t.z * t.z; t.w = t.w * t.w; }
                 *reinterpret_cast<float4*>(w.tile + (4 * g + h) * kTileStride + c * 4) = t;
             }
-            __syncthreads();
+            LDS_SYNC();
             const uint32_t left = w.d_eff - seg * kSeg;          // dims of this segment
             if (!SCALAR) {
                 const uint32_t steps = left >= kSeg ? 16u : (left >> 2);
@@ -345,7 +374,7 @@ __device__ __forceinline__ float chain_rows(const WaveCtx& w, uint32_t s0, const
                     if (seg * kSeg + t < w.d4) acc = acc + x; else acc = __builtin_fmaf(x, x, acc);
                 }
             }
-            __syncthreads();
+            LDS_SYNC();
         }
     }
     return acc;
@@ -404,7 +433,7 @@ __device__ __forceinline__ void compute_distances(const WaveCtx& w, uint32_t m)
             finish_rows<SCALAR>(w, m, b0, acc);
         }
     }
-    __syncthreads();
+    LDS_SYNC();
 }
 
 // WR = 0: the result list W is the libstdc++ max-heap in LDS, maintained exactly as the
@@ -428,12 +457,18 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
     w.nb_id = smem + kTileDwords + a.qpad;
     w.nb_dist = reinterpret_cast<float*>(w.nb_id + 64);
     w.nb_slot = w.nb_id + 128;
-    uint2* W = reinterpret_cast<uint2*>(w.nb_id + 192);
-    uint2* C = W + a.cap_w;
+    // W in LDS: the exact-heap mode keeps it there throughout; the register mode only needs it
+    // for the final sort, after the last use of the tile, so it shares the tile's space
+    uint2* W = WR == 0 ? reinterpret_cast<uint2*>(w.nb_id + 192) : reinterpret_cast<uint2*>(smem);
+    uint2* C = reinterpret_cast<uint2*>(w.nb_id + 192) + (WR == 0 ? a.cap_w : 0u);
     uint32_t* hash = reinterpret_cast<uint32_t*>(C + a.cap_c);
     const uint32_t H = 1u << a.hash_bits, hmask = H - 1, hshift = 32 - a.hash_bits;
     const uint32_t visit_limit = H - (H >> 3);       // keep the table at most 7/8 full
     w.vectors = a.g.vectors; w.row_stride = a.g.row_stride; w.lane = lane;
+    {
+        const unsigned long long tb = (unsigned long long)a.g.n * a.g.row_stride * 4ull;
+        w.table_bytes = tb < 0xFFFFFFF0ull ? (uint32_t)tb : 0u;
+    }
     w.d_eff = SCALAR ? a.g.d : (a.g.d & ~15u);
     w.nseg = (w.d_eff + kSeg - 1) / kSeg;
     w.d4 = a.g.d & ~3u;
@@ -446,7 +481,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
         for (uint32_t i = lane; i < a.qpad; i += 64) w.qs[i] = i < a.g.d ? q[i] : 0.0f;
         for (uint32_t i = lane; i < H; i += 64) hash[i] = kEmpty;
     }
-    __syncthreads();
+    LDS_SYNC();
 
     hnsw_amd_query_stats st = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t fail = 0;
@@ -460,12 +495,12 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
     uint32_t cur_slot = a.g.top_ep_slot, cur_id = a.g.top_ep_order;
     float cur_dist;
     if (lane == 0) { w.nb_id[0] = cur_id; visited_insert(hash, hmask, hshift, cur_id); }
-    __syncthreads();
+    LDS_SYNC();
     compute_distances<SCALAR>(w, 1);
     cur_dist = w.nb_dist[0];
     st.n_dist = 1;
     uint32_t nvis = 1;
-    __syncthreads();
+    LDS_SYNC();
 
     // ---- greedy descent through layers L..1; visited shared by all of them
     //      (src/hnsw.cpp:403-412, 676-717) ----
@@ -486,7 +521,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
             if (fresh) { w.nb_id[rank] = my_order; w.nb_slot[rank] = my_slot; }
             st.n_sweeps++; st.sum_degu += (uint32_t)__popcll(__ballot(live));
             st.n_dist += m; nvis += m;
-            __syncthreads();
+            LDS_SYNC();
             if (m == 0) continue;
             compute_distances<SCALAR>(w, m);
             // first minimum among the new distances, taken only if it improves (strict <)
@@ -504,7 +539,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
                 change = true;
                 cur_dist = bd; cur_id = w.nb_id[bj]; cur_slot = w.nb_slot[bj];
             }
-            __syncthreads();
+            LDS_SYNC();
         }
         if (!fail) cur_slot = a.g.up_down[base + cur_slot];      // changeLayer, src/hnsw.h:575-587
     }
@@ -517,9 +552,9 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
     float f = 0.0f;
     uint32_t wd[WR > 0 ? WR : 1], wi[WR > 0 ? WR : 1];     // register form of W: distance bits, id
     if (!fail) {
-        __syncthreads();
+        LDS_SYNC();
         for (uint32_t i = lane; i < H; i += 64) hash[i] = kEmpty;
-        __syncthreads();
+        LDS_SYNC();
         if (lane == 0) {
             if (WR == 0) W[0] = make_uint2(__float_as_uint(cur_dist), cur_id);
             C[0] = make_uint2(float_keys ? __float_as_uint(cur_dist) : (uint32_t)trunc_key(cur_dist), cur_id);
@@ -529,7 +564,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
         for (int r = 0; r < (WR > 0 ? WR : 1); r++) { wd[r] = 0; wi[r] = 0; }
         if (WR > 0 && lane == 0) { wd[0] = __float_as_uint(cur_dist); wi[0] = cur_id; }
         nW = 1; nC = 1; nvis = 1; f = cur_dist; st.max_c = 1;
-        __syncthreads();
+        LDS_SYNC();
         while (nC > 0) {
             DIAG_STAMP(t0);
             uint32_t ckey, cid;
@@ -544,7 +579,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
                     else if (lane == 0) c_pop(C, nC);
                 }
                 nC--;
-                __syncthreads();
+                LDS_SYNC();
             }
             DIAG_STAMP(t1);
             DIAG_ADD(cy_pop, t0, t1);
@@ -559,7 +594,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
             if (fresh) w.nb_id[rank] = my;
             st.n_expand++; st.sum_deg0 += (uint32_t)__popcll(__ballot(live));
             st.n_dist += m; nvis += m;
-            __syncthreads();
+            LDS_SYNC();
             DIAG_STAMP(t2);
             DIAG_ADD(cy_adj, t1, t2);
             if (m == 0) continue;
@@ -605,18 +640,18 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
                             }
                             f = __uint_as_float(wave_max_u32(mx));   // non-negative floats order as their bit patterns
                         }
-                        __syncthreads();
+                        LDS_SYNC();
                     } else {
                     nW++;
                     if (nC <= kWaveHeapMax && nW <= kWaveHeapMax) {
                         heap_push_wave<COrder>(C, nC, ce, lane);
                         heap_push_wave<WOrder>(W, nW, we, lane);
-                        __syncthreads();
+                        LDS_SYNC();
                         if (nW > ef) {
                             const uint2 root = heap_pop_wave<WOrder>(W, nW, lane);
                             nW--;
                             f = __uint_as_float(root.x);
-                            __syncthreads();
+                            LDS_SYNC();
                         } else {
                             f = __uint_as_float(W[0].x);
                         }
@@ -627,7 +662,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
                             if (nW > ef) w_pop(W, nW);
                         }
                         if (nW > ef) nW--;
-                        __syncthreads();
+                        LDS_SYNC();
                         f = __uint_as_float(W[0].x);
                     }
                     }
@@ -635,7 +670,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
                 }
             }
             nW = rfl(nW); nC = rfl(nC); f = rflf(f); st.max_c = rfl(st.max_c);
-            __syncthreads();
+            LDS_SYNC();
             DIAG_STAMP(t4);
             DIAG_ADD(cy_adm, t3, t4);
         }
@@ -653,12 +688,12 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
     }
 
     // ---- sort W ascending by (distance, id) (src/hnsw.cpp:447) and write the first out_k ----
-    __syncthreads();
+    LDS_SYNC();
     if (WR > 0) {
 #pragma unroll
         for (int r = 0; r < WR; r++)
             if ((uint32_t)(r * 64 + lane) < nW) W[r * 64 + lane] = make_uint2(wd[r], wi[r]);
-        __syncthreads();
+        LDS_SYNC();
     }
     for (uint32_t i = lane; i < nW; i += 64) {
         const uint2 me = W[i];
@@ -695,9 +730,10 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
 
 }  // namespace
 
-size_t search_lds_bytes(const SearchArgs& a)
+size_t search_lds_bytes(const SearchArgs& a, bool w_in_lds)
 {
-    size_t dwords = (size_t)kTileDwords + a.qpad + 192 + 2 * (size_t)a.cap_w + 2 * (size_t)a.cap_c + ((size_t)1 << a.hash_bits);
+    size_t dwords = (size_t)kTileDwords + a.qpad + 192 + (w_in_lds ? 2 * (size_t)a.cap_w : 0) + 2 * (size_t)a.cap_c +
+                    ((size_t)1 << a.hash_bits);
     return dwords * 4;
 }
 
@@ -770,7 +806,7 @@ static ScratchTier tier_for(int ef, int tier)
     uint32_t want_visit = (uint32_t)ef * 28u + 256u;
     uint32_t bits = 10;
     while ((1u << bits) - (1u << (bits - 3)) < want_visit + 64) bits++;
-    uint32_t cap_c = ((uint32_t)ef * 4u + 127u) & ~63u;
+    uint32_t cap_c = ((uint32_t)ef * 4u + 63u) & ~63u;
     bits += (uint32_t)tier;
     cap_c <<= tier;
     return ScratchTier{bits, cap_c};
@@ -810,7 +846,9 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
     for (int tier = 0;; tier++) {
         ScratchTier t = tier_for(ef, tier);
         a.hash_bits = t.hash_bits; a.cap_c = t.cap_c;
-        size_t lds = search_lds_bytes(a);
+        const bool std_heap = (flags & HNSW_AMD_W_STD_HEAP) != 0 || ef > 256;
+        if (!std_heap && 2 * (size_t)a.cap_w > (size_t)kTileDwords) throw std::logic_error("search: W does not fit the tile");
+        size_t lds = search_lds_bytes(a, std_heap);
         if (lds > (size_t)max_lds) {
             throw std::length_error("search: " + std::to_string(a.nq_launch) +
                                     " queries outgrew the largest on-chip scratch configuration (ef too large for LDS?)");
@@ -818,11 +856,17 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
         a.fail_count = cur; a.fail_list = cur + 1;
         HIP_CHECK(hipMemsetAsync(cur, 0, 4, stream));
         void (*kern)(SearchArgs);
-        const bool std_heap = (flags & HNSW_AMD_W_STD_HEAP) != 0 || ef > 256;
         if (scalar) kern = std_heap ? hnsw_search_kernel<true, 0> : (ef <= 64 ? hnsw_search_kernel<true, 1> : (ef <= 128 ? hnsw_search_kernel<true, 2> : hnsw_search_kernel<true, 4>));
         else kern = std_heap ? hnsw_search_kernel<false, 0> : (ef <= 64 ? hnsw_search_kernel<false, 1> : (ef <= 128 ? hnsw_search_kernel<false, 2> : hnsw_search_kernel<false, 4>));
         if (lds > 32768)
             HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (const char* pad = getenv("HNSW_AMD_LDS_PAD")) lds += (size_t)atoi(pad);      // occupancy experiments
+        if (getenv("HNSW_AMD_VERBOSE")) {
+            int nb = 0;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), 64, lds);
+            fprintf(stderr, "[hnsw_amd] search launch: %u queries, ef=%d, tier %d (hash 2^%u, C %u), LDS %zu B, resident queries per CU %d\n",
+                    a.nq_launch, ef, tier, a.hash_bits, a.cap_c, lds, nb);
+        }
         hipLaunchKernelGGL(kern, dim3(a.nq_launch), dim3(64), lds, stream, a);
         HIP_CHECK(hipGetLastError());
         if (!sync_and_retry) return 0;

@@ -1,0 +1,21 @@
+#!/bin/bash
+# PMC passes over tools/run_search.py on the GPU box (each pass its own run, counters only).
+# usage (from the repo root on the box): bash tools/pmc_passes.sh <out-subdir-of-gpurun_out> [run_search args]
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/$1; shift
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd /tmp
+python3 $R/tools/run_search.py --cache /tmp/g1m.npz --reps 1 "$@" > $OUT/prep.log 2>&1 || exit 1
+i=0
+for pass in \
+  "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
+  "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT" \
+  "FETCH_SIZE TCC_HIT_sum" \
+  "WRITE_SIZE TCC_MISS_sum TCC_REQ_sum" \
+  "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" ; do
+  i=$((i+1))
+  timeout -s KILL 120 rocprofv3 --pmc $pass --output-format csv -d $OUT/p$i -- python3 $R/tools/run_search.py --cache /tmp/g1m.npz --reps 2 "$@" > $OUT/p$i.log 2>&1
+  echo "pass $i rc=$?"
+done
