@@ -136,8 +136,16 @@ def main():
     # ---- exact ground truth (brute force on the GPU over every shard, merged) ----
     t0 = time.time()
     base_t = torch.from_numpy(base).to(dev)
-    gd, gi = harness.exact_topk_torch(base_t, q_t, k + 1, id_offset=int(offsets[rank]))
+    gd, gi, gt_info = harness.exact_topk_mfma(base_t, q_t, k + 1, id_offset=int(offsets[rank]))
     del base_t
+    # cross-check of the ground truth on a sample: CPU scan in double precision (N=1 only: needs the whole base)
+    if world == 1:
+        from oracle import oracle as _oracle
+        samp = np.linspace(0, args.nq - 1, 16).astype(int)
+        cpu_gt = _oracle.bruteforce(base, queries[samp], k, threads=min(16, os.cpu_count() or 1)).astype(np.int64)
+        gsub = gi[torch.from_numpy(samp).to(dev)].cpu().numpy()[:, :k]
+        dd = lambda ids: ((queries[samp][:, None, :].astype(np.float64) - base[ids].astype(np.float64)) ** 2).sum(-1)
+        gt_info["cpu_double_check"] = bool(np.array_equal(dd(gsub), dd(cpu_gt)))    # same distances: equal up to exact ties
     if world > 1:
         all_d = [torch.empty_like(gd) for _ in range(world)]
         all_i = [torch.empty_like(gi) for _ in range(world)]
@@ -277,7 +285,8 @@ def main():
             "config": {"workload": f"{args.kind}-{d} synthetic, n={args.n}, nq={nq}, M=16, efConstruction=200, ef={ef}, k={k}, "
                                    f"keys={args.keys}" + (f", {world} shards + RCCL all-gather + device merge" if world > 1 else ""),
                        "ef": ef, "recall_at_10": round(recall, 4), "reference_precision_top11": prec_ref,
-                       "ef_sweep": sweep, "build_s": round(build_s, 1), "build_threads": args.build_threads},
+                       "ef_sweep": sweep, "build_s": round(build_s, 1), "build_threads": args.build_threads,
+                       "ground_truth": dict(gt_info, method="exact brute force, f32-input MFMA kernel of this library")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": "hnsw_search_kernel", "kernel_ms": round(kern_ms, 4),

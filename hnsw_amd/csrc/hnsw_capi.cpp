@@ -18,6 +18,8 @@ using namespace hnsw_amd;
 namespace hnsw_amd {
 void hdf_get_dimensions(const char* filename, const char* dataset, uint64_t dims[2]);
 void hdf_read(const char* filename, const char* dataset, void* data, bool as_float);
+float bruteforce_knn(const float* d_base, uint32_t n, const float* d_queries, uint32_t nq, uint32_t d, uint32_t k,
+                     uint32_t id_offset, uint32_t* d_out_ids, float* d_out_dist, void* stream_v);
 void merge_topk(const float* d_dist, const uint32_t* d_ids, const uint32_t* shard_offset, uint32_t S, uint32_t nq, uint32_t k,
                 uint32_t out_k, uint32_t* d_out_ids, float* d_out_dist, void* stream);
 }
@@ -234,6 +236,15 @@ int hnsw_amd_hdf_read_float(const char* filename, const char* dataset, float* da
 int hnsw_amd_hdf_read_int(const char* filename, const char* dataset, int* data)
 {
     return guarded([&] { REQUIRE(filename && dataset && data, "hdf_read_int: NULL argument"); hdf_read(filename, dataset, data, false); });
+}
+
+int hnsw_amd_bruteforce_knn_device(const float* d_base, uint32_t n, const float* d_queries, uint32_t nq, uint32_t d, uint32_t k,
+                                   uint32_t id_offset, uint32_t* d_out_ids, float* d_out_dist, void* stream, float* mfma_ms)
+{
+    return guarded([&] {
+        float ms = bruteforce_knn(d_base, n, d_queries, nq, d, k, id_offset, d_out_ids, d_out_dist, stream);
+        if (mfma_ms) *mfma_ms = ms;
+    });
 }
 
 int hnsw_amd_merge_topk_device(const float* d_dist, const uint32_t* d_ids, const uint32_t* shard_offset, uint32_t n_shards,

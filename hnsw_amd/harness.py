@@ -54,3 +54,29 @@ def exact_topk_torch(base_t, queries_t, k: int, chunk: int = 1 << 18, id_offset:
         dd2, sel = torch.topk(cat_d, k, dim=1, largest=False)
         best_d, best_i = dd2, torch.gather(cat_i, 1, sel)
     return best_d, best_i
+
+
+F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X, f32-input MFMA (spec)
+
+
+def exact_topk_mfma(base_t, queries_t, k: int, id_offset: int = 0):
+    """Exact k nearest rows with the library's own brute-force kernels (f32-input MFMA for the
+    dot products).  Tensors on the current GPU, float32, contiguous.  Returns
+    (dist [nq,k] f32 tensor, ids [nq,k] int64 tensor, info dict with the MFMA kernel's rate)."""
+    import ctypes as C
+
+    import torch
+
+    from . import capi
+    n, d = base_t.shape
+    nq = queries_t.shape[0]
+    out_i = torch.empty((nq, k), dtype=torch.int32, device=queries_t.device)
+    out_d = torch.empty((nq, k), dtype=torch.float32, device=queries_t.device)
+    ms = C.c_float(0.0)
+    capi.check(capi.lib().hnsw_amd_bruteforce_knn_device(base_t.data_ptr(), n, queries_t.data_ptr(), nq, d, k, id_offset,
+                                                         out_i.data_ptr(), out_d.data_ptr(),
+                                                         torch.cuda.current_stream().cuda_stream, C.byref(ms)))
+    tflops = 2.0 * nq * n * d / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+    info = {"mfma_kernel_ms": round(ms.value, 3), "tflops": round(tflops, 2), "peak_tflops": F32_MFMA_PEAK_TFLOPS,
+            "mfma_frac": round(tflops / F32_MFMA_PEAK_TFLOPS, 4)}
+    return out_d, out_i.to(torch.int64) & 0xFFFFFFFF, info

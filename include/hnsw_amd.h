@@ -144,6 +144,16 @@ int hnsw_amd_hdf_get_dimensions(const char* filename, const char* dataset, uint6
 int hnsw_amd_hdf_read_float(const char* filename, const char* dataset, float* data);
 int hnsw_amd_hdf_read_int(const char* filename, const char* dataset, int* data);
 
+/* Exact k nearest base rows of every query by squared L2 (brute force), all buffers in
+ * device memory of the current GPU: ground truth for recall figures.  The reference has no
+ * counterpart (it reads ground truth from the dataset's "neighbors" array,
+ * src/main.cpp:190-195).  Output rows ascending by (distance, id), ids offset by id_offset,
+ * k <= 128.  The q.x products run on the matrix cores (f32-input MFMA); *mfma_ms (host, may be
+ * NULL) receives the device time of that kernel: 2*nq*n*d flop / mfma_ms is its rate.
+ * Synchronises the stream. */
+int hnsw_amd_bruteforce_knn_device(const float* d_base, uint32_t n, const float* d_queries, uint32_t nq, uint32_t d, uint32_t k,
+                                   uint32_t id_offset, uint32_t* d_out_ids, float* d_out_dist, void* stream, float* mfma_ms);
+
 /* Sharded multi-GPU search, combine step (no counterpart in the reference, which is one
  * in-memory index): d_dist / d_ids hold n_shards per-shard result blocks of nq x k each
  * (ids local to the shard, 0xFFFFFFFF = padding), as an all-gather leaves them;
