@@ -94,7 +94,11 @@ def main():
         log(f"rank {rank}: graph loaded from {cpath} in {time.time() - t0:.1f}s")
     else:
         h.init(d, hi - lo)
-        h.insert_batch(base, threads=args.build_threads)
+        step_rows = 500_000       # in pieces, so a long build keeps reporting progress
+        for r0 in range(0, hi - lo, step_rows):
+            h.insert_batch(base[r0:r0 + step_rows], threads=args.build_threads)
+            if hi - lo > step_rows:
+                log(f"rank {rank}: inserted {min(hi - lo, r0 + step_rows)} / {hi - lo} in {time.time() - t0:.0f}s")
         log(f"rank {rank}: built {hi - lo} vectors with {args.build_threads} threads in {time.time() - t0:.1f}s")
         if cpath:
             os.makedirs(cache, exist_ok=True)
@@ -160,7 +164,9 @@ def main():
     # ---- ef: the reference's sweep, smallest ef reaching the target recall@10 ----
     sweep = []
     ef_pick = args.ef
-    for ef in ([args.ef] if args.ef else harness.REFERENCE_EF_SWEEP):
+    # shards see fewer points each, so a sharded run may reach the target below the reference's first value (20)
+    sweep_values = harness.REFERENCE_EF_SWEEP if world == 1 else [10, 12, 14, 16, 18] + harness.REFERENCE_EF_SWEEP
+    for ef in ([args.ef] if args.ef else sweep_values):
         step(ef, k)
         torch.cuda.synchronize()
         ids = out_ids.cpu().numpy().astype(np.int64) & 0xFFFFFFFF

@@ -73,7 +73,7 @@ class HnswAmdError(RuntimeError):
 def lib():
     global _LIB
     if _LIB is None:
-        if not os.path.exists(LIB_PATH):
+        if not os.path.exists(LIB_PATH):  # the message below is part of the contract: tests look for it
             raise ImportError(f"{LIB_PATH} is missing: build it with `python -m hnsw_amd.build` (there is no CPU fallback)")
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():

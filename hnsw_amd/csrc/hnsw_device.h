@@ -56,6 +56,9 @@ public:
     uint32_t* d_fail = nullptr;       // [0] = count, [1..] list
     uint32_t fail_cap = 0;
     uint32_t* h_fail = nullptr;       // pinned host mirror of d_fail[0]
+    // scratch tier most queries of the last batch needed, and the ef / flags it was learnt at
+    int hint_tier = 0, hint_ef = 0;
+    uint32_t hint_flags = 0;
 
     ~DeviceIndex();
     void release();

@@ -796,6 +796,7 @@ void DeviceIndex::upload(const HostIndex& h, int dev)
     g.up_adj_order = to_device(fg.up_adj_order, bufs_[5]);
     HIP_CHECK(hipDeviceSynchronize());
     version = h.version_;
+    hint_tier = 0; hint_ef = 0; hint_flags = 0;
 }
 
 static ScratchTier tier_for(int ef, int tier)
@@ -843,7 +844,12 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
     uint32_t retried = 0;
     uint32_t* cur = d_fail;
     uint32_t* other = d_fail_alt;
-    for (int tier = 0;; tier++) {
+    // Start where most queries of the previous batch at a comparable ef ended up: on data where
+    // the search visits far more nodes than the tier-0 estimate (unit-norm vectors with the
+    // reference's int32 keys), running every query twice would double the work.
+    const int first_tier = (hint_tier > 0 && 4 * ef >= 3 * hint_ef && flags == hint_flags) ? hint_tier : 0;
+    int crowded_tier = first_tier;
+    for (int tier = first_tier;; tier++) {
         ScratchTier t = tier_for(ef, tier);
         a.hash_bits = t.hash_bits; a.cap_c = t.cap_c;
         const bool std_heap = (flags & HNSW_AMD_W_STD_HEAP) != 0 || ef > 256;
@@ -873,11 +879,13 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
         HIP_CHECK(hipMemcpyAsync(h_fail, cur, 4, hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
         uint32_t nfail = h_fail[0];
+        if (8 * (size_t)nfail >= nq) crowded_tier = tier + 1;      // an eighth of the batch or more needs the next tier
         if (nfail == 0) break;
         retried += nfail;
         a.qmap = cur + 1; a.nq_launch = nfail;
         std::swap(cur, other);
     }
+    if (crowded_tier != first_tier || first_tier == 0) { hint_tier = crowded_tier; hint_ef = ef; hint_flags = flags; }
     return retried;
 }
 

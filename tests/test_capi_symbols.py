@@ -34,3 +34,25 @@ def test_argument_errors_are_status_codes_not_crashes():
     assert L.hnsw_amd_load_graph(h, b"/nonexistent/graph.bin") == capi.E_IO
     assert L.hnsw_amd_insert(h, None) == capi.E_ARG
     L.hnsw_amd_destroy(h)
+
+
+def test_missing_library_fails_loudly():
+    """There is no CPU fallback: without libhnsw_amd.so the package refuses to work."""
+    import subprocess
+    import sys
+    code = ("import os,sys; sys.path.insert(0, %r); os.environ['HNSW_AMD_LIB']='/nonexistent/libhnsw_amd.so';"
+            "from hnsw_amd import capi\n"
+            "try:\n    capi.lib()\nexcept ImportError as e:\n    print('REFUSED', e)\n" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert "REFUSED" in out.stdout and "no CPU fallback" in out.stdout
+
+
+def test_product_package_never_imports_the_oracle():
+    import re
+    pkg = os.path.join(ROOT, "hnsw_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+                assert "liboracle" not in text, f

@@ -102,3 +102,37 @@ def test_scratch_overflow_is_retried_transparently():
     oi, od, oc = idx.search(g.queries, 200)
     assert np.array_equal(cnt, oc)
     assert_same_results(ids, dist, oi, od, what="ef=200")
+
+
+def test_search_argument_errors():
+    h = HNSW(16, 16, 200)
+    h.init(8, 10)
+    q = np.zeros((2, 8), np.float32)
+    with pytest.raises(capi.HnswAmdError) as e:          # nothing inserted yet
+        h.search_batch(q, 10)
+    assert e.value.code == capi.E_ARG
+    h.insert_batch(np.arange(80, dtype=np.float32).reshape(10, 8))
+    with pytest.raises(capi.HnswAmdError) as e:          # out_k > ef
+        h.search_batch(q, 4, out_k=8)
+    assert e.value.code == capi.E_ARG
+    with pytest.raises(capi.HnswAmdError) as e:          # an ef no on-chip scratch tier can hold
+        h.search_batch(q, 100000)
+    assert e.value.code == capi.E_SCRATCH
+    ids, dist, cnt = h.search_batch(q, 10)               # and the index still works
+    assert (cnt == 10).all() and sorted(ids[0].tolist()) == list(range(10))
+
+
+def test_index_can_grow_between_searches():
+    base = np.random.default_rng(1).integers(0, 100, size=(400, 16)).astype(np.float32)
+    q = base[:5] + 0.0
+    h = HNSW(16, 16, 200)
+    h.init(16, 400)
+    h.insert_batch(base[:200])
+    ids1, _, _ = h.search_batch(q, 20, out_k=1)
+    assert (ids1[:, 0] == np.arange(5)).all()
+    h.insert_batch(base[200:])
+    idx = oracle.OracleIndex(h.export_flat(), base)
+    ids, dist, cnt = h.search_batch(base[300:310], 20)
+    oi, od, oc = idx.search(base[300:310], 20)
+    assert_same_results(ids, dist, oi, od, what="after growth")
+    assert (ids[:, 0] == np.arange(300, 310)).all() or (dist[:, 0] == 0).all()

@@ -1,0 +1,44 @@
+"""GPU: the sharded layout on one device — every shard's sub-graph searched by the kernel, the
+per-shard lists merged by the device kernel — against per-shard CPU restatement + host merge."""
+import numpy as np
+import pytest
+
+from hnsw_amd import HNSW, capi, datagen
+from hnsw_amd.sharded import merge_topk_numpy, shard_offsets, shard_range
+from oracle import oracle
+from tests.helpers import assert_same_results, recall_at_k
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("S", [2, 5])
+def test_sharded_search_and_device_merge(S):
+    import torch
+    n, d, nq, ef, k = 30000, 128, 200, 32, 10
+    base = datagen.make("sift", n, seed=6)
+    q = datagen.make("sift", nq, seed=6, stream=1)
+    offs = shard_offsets(n, S)
+    g_d = torch.empty((S, nq, k), dtype=torch.float32, device="cuda")
+    g_i = torch.empty((S, nq, k), dtype=torch.int32, device="cuda")
+    q_t = torch.from_numpy(q).cuda()
+    exp_i, exp_d = [], []
+    keep = []
+    for s in range(S):
+        lo, hi = shard_range(n, s, S)
+        h = HNSW(16, 16, 200)
+        h.init(d, hi - lo)
+        h.insert_batch(base[lo:hi], threads=8)
+        keep.append(h)
+        h.sync_device(0)
+        h.search_batch_device(q_t.data_ptr(), nq, ef, k, g_i[s].data_ptr(), g_d[s].data_ptr(), 0, 0, torch.cuda.current_stream().cuda_stream)
+        oi, od, _ = oracle.OracleIndex(h.export_flat(), base[lo:hi]).search(q, ef, out_k=k)
+        exp_i.append(oi); exp_d.append(od)
+    o_i = torch.empty((nq, k), dtype=torch.int32, device="cuda")
+    o_d = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+    capi.check(capi.lib().hnsw_amd_merge_topk_device(g_d.data_ptr(), g_i.data_ptr(), capi.u32(offs), S, nq, k, k, o_i.data_ptr(),
+                                                     o_d.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    eg, ed = merge_topk_numpy(np.stack(exp_d), np.stack(exp_i), offs, k)
+    assert_same_results(o_i.cpu().numpy().view(np.uint32), o_d.cpu().numpy(), eg, ed, what=f"{S} shards")
+    gt = oracle.bruteforce(base, q, k, threads=8)
+    assert recall_at_k(eg, gt, k) > 0.9

@@ -19,20 +19,27 @@ ap.add_argument("--ef", type=int, default=50)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--threads", type=int, default=16)
 ap.add_argument("--cache", default="")
+ap.add_argument("--kind", default="sift")
+ap.add_argument("--keys", default="int32")
 a = ap.parse_args()
-base = datagen.make("sift", a.n, seed=1)
-q = datagen.make("sift", a.nq, seed=1, stream=1)
+base = datagen.make(a.kind, a.n, seed=1)
+q = datagen.make(a.kind, a.nq, seed=1, stream=1)
 h = HNSW(16, 16, 200)
 if a.cache and os.path.exists(a.cache):
     h.import_flat(FlatGraph.from_npz(np.load(a.cache)), base)
 else:
-    h.init(128, a.n)
+    h.init(base.shape[1], a.n)
     t = time.time(); h.insert_batch(base, threads=a.threads); print(f"build {time.time()-t:.1f}s", flush=True)
     if a.cache:
         np.savez(a.cache, **h.export_flat().to_npz_dict())
 h.sync_device(0)
 for rep in range(a.reps):
     t = time.time()
+    from hnsw_amd import capi
+    h.flags = capi.DIST_SSE | (capi.KEYS_FLOAT if a.keys == "float" else capi.KEYS_INT32)
     ids, ds, cnt, st = h.search_batch(q, a.ef, out_k=10, stats=True)
     print(f"rep {rep}: host wall {1e3*(time.time()-t):.2f} ms", flush=True)
 print("n_dist/q", st["n_dist"].mean(), "expansions/q", st["n_expand"].mean())
+for f in ("max_c", "n_visited0", "n_expand", "n_dist"):
+    v = st[f]
+    print(f, "mean", v.mean(), "p50", np.percentile(v, 50), "p99", np.percentile(v, 99), "max", v.max())
