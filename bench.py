@@ -45,7 +45,8 @@ def main():
     ap.add_argument("--ef", type=int, default=0, help="0 = smallest ef of the reference sweep with recall@10 >= target")
     ap.add_argument("--target-recall", type=float, default=0.95)
     ap.add_argument("--build-threads", type=int, default=16)
-    ap.add_argument("--cpu-baseline", default="port", choices=["port", "reference", "none"])
+    ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "port", "reference", "none"],
+                    help="auto: the unmodified reference binary (oracle/_ref) when present, else the CPU restatement")
     ap.add_argument("--cpu-sample", type=int, default=4000)
     ap.add_argument("--keys", default="int32", choices=["int32", "float"])
     args = ap.parse_args()
@@ -252,20 +253,40 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and args.cpu_baseline != "none":
         ns = min(args.cpu_sample, nq)
-        if args.cpu_baseline == "reference":
-            drv = os.path.join(ROOT, "oracle", "_ref", "ref_driver_sse")
+        from oracle import oracle
+        from tests.helpers import assert_same_results
+        mode = args.cpu_baseline
+        if mode == "auto":
+            mode = "reference" if oracle.ref_driver_path() else "port"
+        if mode == "reference":
+            drv = oracle.ref_driver_path()
             with tempfile.TemporaryDirectory() as tmp:
-                gpath, qpath = os.path.join(tmp, "g.bin"), os.path.join(tmp, "q.bin")
-                h.saveGraph(gpath)
+                gpath, qpath, rpath = (os.path.join(tmp, x) for x in ("g.bin", "q.bin", "r.bin"))
+                t0 = time.time()
+                h.saveGraph(gpath)            # the reference's own file format
                 queries[:ns].tofile(qpath)
                 out = subprocess.run([drv, "ltime", gpath, "16", "16", "200", qpath, str(ns), str(ef), "30"],
                                      capture_output=True, text=True, check=True).stderr
-            rec = json.loads(out.strip().splitlines()[-1])
+                rec = json.loads(out.strip().splitlines()[-1])
+                # full-size parity against the reference itself: its W_ for a sample of the queries
+                npar = min(1000, ns)
+                subprocess.run([drv, "lquery", gpath, "16", "16", "200", qpath, str(npar), rpath, str(ef)], check=True,
+                               capture_output=True)
+                r_ids, r_d, _ = oracle.parse_ref_results(rpath)[ef]
+                log(f"reference binary: save + load + timing + {npar}-query dump in {time.time() - t0:.1f}s")
+            g_ids = out_ids.cpu().numpy().view(np.uint32)[:npar]
+            g_d = out_dist.cpu().numpy()[:npar]
+            try:
+                assert_same_results(g_ids, g_d, r_ids[:, :k], r_d[:, :k], what="GPU vs reference binary")
+                same = True
+            except AssertionError as e:
+                log(f"PARITY FAILURE against the reference binary: {e}")
+                same = False
             cpu = {"value": round(rec["qps"], 1), "unit": "queries/s", "cores": 1, "kind": "reference",
-                   "sample": f"first {ns} queries, ef={ef}, min of {rec['passes']} passes; unmodified reference binary, "
-                             f"index read by its own loadGraph from the file this library saved"}
+                   "sample": f"first {ns} queries, ef={ef}, min of {rec['passes']} passes, 1 thread; unmodified reference binary, "
+                             f"index read by its own loadGraph from the file this library saved",
+                   "gpu_top10_equals_reference_on_first": npar, "parity": same}
         else:
-            from oracle import oracle
             idx = oracle.OracleIndex(h.export_flat(), base)
             best = 1e30
             for _ in range(3):

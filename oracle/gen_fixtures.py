@@ -84,27 +84,7 @@ def parse_graph(path: str) -> FlatGraph:
                      ep_slot=u(ep_slot), ep_order=u(ep_order))
 
 
-def parse_results(path: str):
-    with open(path, "rb") as f:
-        buf = f.read()
-    magic, nq, nef = struct.unpack_from("<III", buf, 0)
-    assert magic == 0x31535248
-    pos = 12
-    out = {}
-    for _ in range(nef):
-        (ef,) = struct.unpack_from("<I", buf, pos); pos += 4
-        ids = np.full((nq, ef), PAD, np.uint32)
-        ds = np.full((nq, ef), np.inf, np.float32)
-        cnt = np.zeros(nq, np.uint32)
-        for i in range(nq):
-            (c,) = struct.unpack_from("<I", buf, pos); pos += 4
-            assert c <= ef
-            ids[i, :c] = np.frombuffer(buf, "<u4", c, pos); pos += 4 * c
-            ds[i, :c] = np.frombuffer(buf, "<f4", c, pos); pos += 4 * c
-            cnt[i] = c
-        out[ef] = (ids, ds, cnt)
-    assert pos == len(buf)
-    return out
+from oracle.oracle import parse_ref_results as parse_results  # noqa: E402
 
 
 def make_data(case):

@@ -100,3 +100,33 @@ def bruteforce(base: np.ndarray, queries: np.ndarray, k: int, threads: int = 8) 
     out = np.empty((q.shape[0], k), np.uint32)
     lib().oracle_bruteforce(_p(b, _f32p), b.shape[0], b.shape[1], _p(q, _f32p), q.shape[0], k, _p(out, _u32p), threads)
     return out
+
+
+def parse_ref_results(path: str):
+    """Read a results file written by oracle/_ref/ref_driver_* (modes query / lquery):
+    {ef: (ids [nq,ef] u32, dists [nq,ef] f32, counts [nq] u32)}, rows padded with 0xFFFFFFFF / +inf."""
+    import struct
+    with open(path, "rb") as f:
+        buf = f.read()
+    magic, nq, nef = struct.unpack_from("<III", buf, 0)
+    assert magic == 0x31535248, "not a ref_driver results file"
+    pos = 12
+    out = {}
+    for _ in range(nef):
+        (ef,) = struct.unpack_from("<I", buf, pos); pos += 4
+        ids = np.full((nq, ef), 0xFFFFFFFF, np.uint32)
+        ds = np.full((nq, ef), np.inf, np.float32)
+        cnt = np.zeros(nq, np.uint32)
+        for i in range(nq):
+            (c,) = struct.unpack_from("<I", buf, pos); pos += 4
+            ids[i, :c] = np.frombuffer(buf, "<u4", c, pos); pos += 4 * c
+            ds[i, :c] = np.frombuffer(buf, "<f4", c, pos); pos += 4 * c
+            cnt[i] = c
+        out[ef] = (ids, ds, cnt)
+    return out
+
+
+def ref_driver_path(build: str = "sse"):
+    """The unmodified reference compiled by oracle/Makefile, if it is present and executable."""
+    p = os.path.join(_HERE, "_ref", f"ref_driver_{build}")
+    return p if os.path.exists(p) and os.access(p, os.X_OK) else None
