@@ -49,6 +49,9 @@ def main():
                     help="auto: the unmodified reference binary (oracle/_ref) when present, else the CPU restatement")
     ap.add_argument("--cpu-sample", type=int, default=4000)
     ap.add_argument("--keys", default="int32", choices=["int32", "float"])
+    ap.add_argument("--dist", default="sse", choices=["sse", "scalar"],
+                    help="sse: the shipped reference's distance (first 16*floor(d/16) dims); scalar: its -DNO_MANUAL_VECTORIZATION build (all dims)")
+    ap.add_argument("--sweep", default="", help="comma-separated ef values: report recall and QPS for each instead of one operating point")
     args = ap.parse_args()
 
     import torch
@@ -115,7 +118,7 @@ def main():
     dist_t = torch.empty((nq, EFMAX), dtype=torch.float32, device=dev)
     cnt_t = torch.empty((nq,), dtype=torch.int32, device=dev)
     stats_t = torch.empty((nq, 8), dtype=torch.int32, device=dev)
-    flags = capi.DIST_SSE | (capi.KEYS_FLOAT if args.keys == "float" else capi.KEYS_INT32)
+    flags = (capi.DIST_SCALAR if args.dist == "scalar" else capi.DIST_SSE) | (capi.KEYS_FLOAT if args.keys == "float" else capi.KEYS_INT32)
     h.flags = flags
     offsets = np.array([r * args.n // world for r in range(world)], dtype=np.uint32)
     out_ids = torch.empty((nq, k), dtype=torch.int32, device=dev)
@@ -162,6 +165,34 @@ def main():
     gt = gi.cpu().numpy()
     log(f"ground truth in {time.time() - t0:.1f}s")
 
+    if args.sweep:
+        rows = []
+        for ef in [int(x) for x in args.sweep.split(",")]:
+            step(ef, k, want_stats=(world == 1))
+            torch.cuda.synchronize()
+            ids = out_ids.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+            rec = {"ef": ef, "recall_at_10": round(harness.recall_at_k(ids, gt, k), 4)}
+            if world == 1:
+                st = stats_t.cpu().numpy().view(np.uint32).reshape(nq, 8).copy().view(capi.STATS_DTYPE).reshape(nq)
+                rec["dist_per_query"] = round(float(st["n_dist"].mean()), 1)
+                bpl = int(harness.algorithmic_bytes(st, d, d if args.dist == "scalar" else d & ~15, k).sum())
+            t0 = time.perf_counter()
+            for _ in range(3):
+                step(ef, k)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 3
+            rec["qps"] = round(nq / dt, 1)
+            if world == 1:
+                rec["algorithmic_gbs"] = round(bpl / dt / 1e9, 1)
+            rows.append(rec)
+            log(f"sweep {rec}")
+        if rank == 0:
+            print(json.dumps({"workload": f"{args.kind}-{d} synthetic, n={args.n}, nq={nq}, keys={args.keys}, dist={args.dist}",
+                              "n_gpus": world, "build_s": round(build_s, 1), "ground_truth": gt_info, "sweep": rows}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
     # ---- ef: the reference's sweep, smallest ef reaching the target recall@10 ----
     sweep = []
     ef_pick = args.ef
@@ -185,7 +216,7 @@ def main():
     step(ef, k, want_stats=True)
     torch.cuda.synchronize()
     st = stats_t.cpu().numpy().view(np.uint32).reshape(nq, 8).copy().view(capi.STATS_DTYPE).reshape(nq)
-    bytes_per_launch = int(harness.algorithmic_bytes(st, d, d & ~15, k).sum())
+    bytes_per_launch = int(harness.algorithmic_bytes(st, d, d if args.dist == "scalar" else d & ~15, k).sum())
     ids_final = out_ids.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
     # top-(k+1) for the reference's own "Precision" figure
     prec_ref = None
@@ -256,52 +287,74 @@ def main():
         from oracle import oracle
         from tests.helpers import assert_same_results
         mode = args.cpu_baseline
+        build_kind = "scalar" if args.dist == "scalar" else "sse"
         if mode == "auto":
-            mode = "reference" if oracle.ref_driver_path() else "port"
+            mode = "reference" if oracle.ref_driver_path(build_kind) else "port"
+        if mode == "reference" and args.keys == "float":
+            mode = "port"      # the reference has no float-key mode
+        ref_note = None
         if mode == "reference":
-            drv = oracle.ref_driver_path()
-            with tempfile.TemporaryDirectory() as tmp:
-                gpath, qpath, rpath = (os.path.join(tmp, x) for x in ("g.bin", "q.bin", "r.bin"))
-                t0 = time.time()
-                h.saveGraph(gpath)            # the reference's own file format
-                queries[:ns].tofile(qpath)
-                out = subprocess.run([drv, "ltime", gpath, "16", "16", "200", qpath, str(ns), str(ef), "30"],
-                                     capture_output=True, text=True, check=True).stderr
-                rec = json.loads(out.strip().splitlines()[-1])
-                # full-size parity against the reference itself: its W_ for a sample of the queries
-                npar = min(1000, ns)
-                subprocess.run([drv, "lquery", gpath, "16", "16", "200", qpath, str(npar), rpath, str(ef)], check=True,
-                               capture_output=True)
-                r_ids, r_d, _ = oracle.parse_ref_results(rpath)[ef]
-                log(f"reference binary: save + load + timing + {npar}-query dump in {time.time() - t0:.1f}s")
-            g_ids = out_ids.cpu().numpy().view(np.uint32)[:npar]
-            g_d = out_dist.cpu().numpy()[:npar]
+            drv = oracle.ref_driver_path(build_kind)
             try:
-                assert_same_results(g_ids, g_d, r_ids[:, :k], r_d[:, :k], what="GPU vs reference binary")
-                same = True
-            except AssertionError as e:
-                log(f"PARITY FAILURE against the reference binary: {e}")
-                same = False
-            cpu = {"value": round(rec["qps"], 1), "unit": "queries/s", "cores": 1, "kind": "reference",
-                   "sample": f"first {ns} queries, ef={ef}, min of {rec['passes']} passes, 1 thread; unmodified reference binary, "
-                             f"index read by its own loadGraph from the file this library saved",
-                   "gpu_top10_equals_reference_on_first": npar, "parity": same}
-        else:
+                with tempfile.TemporaryDirectory() as tmp:
+                    _probe = subprocess.run([drv], capture_output=True, timeout=20)     # does the binary run on this host at all?
+            except Exception as e:      # noqa: BLE001
+                ref_note = f"reference binary not runnable here ({type(e).__name__})"
+                mode = "port"
+        if mode == "reference":
+            try:
+                with tempfile.TemporaryDirectory() as tmp:
+                    gpath, qpath, rpath = (os.path.join(tmp, x) for x in ("g.bin", "q.bin", "r.bin"))
+                    t0 = time.time()
+                    h.saveGraph(gpath)            # the reference's own file format
+                    queries[:ns].tofile(qpath)
+                    # (the reference's visited table has no overflow check, src/hnsw.h:90-107: it never returns
+                    # from a query that visits 16384 nodes — hence the time limits)
+                    out = subprocess.run([drv, "ltime", gpath, "16", "16", "200", qpath, str(ns), str(ef), "30"],
+                                         capture_output=True, text=True, check=True, timeout=150).stderr
+                    rec = json.loads(out.strip().splitlines()[-1])
+                    # full-size parity against the reference itself: its W_ for a sample of the queries
+                    npar = min(1000, ns)
+                    subprocess.run([drv, "lquery", gpath, "16", "16", "200", qpath, str(npar), rpath, str(ef)], check=True,
+                                   capture_output=True, timeout=150)
+                    r_ids, r_d, _ = oracle.parse_ref_results(rpath)[ef]
+                    log(f"reference binary: save + load + timing + {npar}-query dump in {time.time() - t0:.1f}s")
+                g_ids = out_ids.cpu().numpy().view(np.uint32)[:npar]
+                g_d = out_dist.cpu().numpy()[:npar]
+                try:
+                    assert_same_results(g_ids, g_d, r_ids[:, :k], r_d[:, :k], what="GPU vs reference binary")
+                    same = True
+                except AssertionError as e:
+                    log(f"PARITY FAILURE against the reference binary: {e}")
+                    same = False
+                cpu = {"value": round(rec["qps"], 1), "unit": "queries/s", "cores": 1, "kind": "reference",
+                       "sample": f"first {ns} queries, ef={ef}, min of {rec['passes']} passes, 1 thread; unmodified reference binary, "
+                                 f"index read by its own loadGraph from the file this library saved",
+                       "gpu_top10_equals_reference_on_first": npar, "parity": same}
+            except (subprocess.TimeoutExpired, subprocess.CalledProcessError) as e:
+                ref_note = (f"reference binary did not finish ({type(e).__name__}); its visited table never returns once a "
+                            f"query visits 16384 nodes (src/hnsw.h:90-107)")
+                log(ref_note)
+                mode = "port"
+        if mode == "port":
             idx = oracle.OracleIndex(h.export_flat(), base)
             best = 1e30
             for _ in range(3):
                 t0 = time.perf_counter()
-                o_ids, o_d, _ = idx.search(queries[:ns], ef, out_k=k, threads=1)
+                o_ids, o_d, _ = idx.search(queries[:ns], ef, out_k=k, threads=1, dist_mode=1 if args.dist == "scalar" else 0,
+                                            key_mode=1 if args.keys == "float" else 0)
                 best = min(best, time.perf_counter() - t0)
             nt = min(16, os.cpu_count() or 1)
             t0 = time.perf_counter()
-            idx.search(queries, ef, out_k=k, threads=nt)
+            idx.search(queries, ef, out_k=k, threads=nt, dist_mode=1 if args.dist == "scalar" else 0, key_mode=1 if args.keys == "float" else 0)
             mt = time.perf_counter() - t0
             same = bool(np.array_equal(o_d, out_dist.cpu().numpy()[:ns]))
             cpu = {"value": round(ns / best, 1), "unit": "queries/s", "cores": 1, "kind": "port",
                    "sample": f"first {ns} queries, ef={ef}, min of 3 passes, 1 thread (CPU restatement, bit-equal to the reference)",
                    "mt": {"value": round(nq / mt, 1), "cores": nt},
                    "gpu_distances_bit_equal_on_sample": same}
+            if ref_note:
+                cpu["note"] = ref_note
 
     if rank == 0:
         out = {

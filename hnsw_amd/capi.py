@@ -57,7 +57,7 @@ SYMBOLS = {
     "hnsw_amd_bruteforce_knn_device": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                                  C.c_void_p, C.c_void_p, C.c_void_p, _f32p]),
     "hnsw_amd_merge_topk_device": (C.c_int, [C.c_void_p, C.c_void_p, _u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
-                                             C.c_void_p, C.c_void_p, C.c_void_p]),
+                                             C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hnsw_amd_get_info": (C.c_int, [C.c_void_p, _i32p, _i32p, _i32p, _i32p, _u32p, _i32p, _i32p, _u32p]),
 }
 

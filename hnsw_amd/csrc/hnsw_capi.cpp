@@ -21,7 +21,7 @@ void hdf_read(const char* filename, const char* dataset, void* data, bool as_flo
 float bruteforce_knn(const float* d_base, uint32_t n, const float* d_queries, uint32_t nq, uint32_t d, uint32_t k,
                      uint32_t id_offset, uint32_t* d_out_ids, float* d_out_dist, void* stream_v);
 void merge_topk(const float* d_dist, const uint32_t* d_ids, const uint32_t* shard_offset, uint32_t S, uint32_t nq, uint32_t k,
-                uint32_t out_k, uint32_t* d_out_ids, float* d_out_dist, void* stream);
+                uint32_t out_k, size_t shard_stride, uint32_t* d_out_ids, float* d_out_dist, void* stream);
 }
 
 struct hnsw_amd_index {
@@ -248,11 +248,12 @@ int hnsw_amd_bruteforce_knn_device(const float* d_base, uint32_t n, const float*
 }
 
 int hnsw_amd_merge_topk_device(const float* d_dist, const uint32_t* d_ids, const uint32_t* shard_offset, uint32_t n_shards,
-                               uint32_t nq, uint32_t k, uint32_t out_k, uint32_t* d_out_ids, float* d_out_dist, void* stream)
+                               uint32_t nq, uint32_t k, uint32_t out_k, uint64_t shard_stride, uint32_t* d_out_ids, float* d_out_dist,
+                               void* stream)
 {
     return guarded([&] {
         REQUIRE(d_dist && d_ids && shard_offset && d_out_ids && d_out_dist, "merge_topk_device: NULL argument");
-        merge_topk(d_dist, d_ids, shard_offset, n_shards, nq, k, out_k, d_out_ids, d_out_dist, stream);
+        merge_topk(d_dist, d_ids, shard_offset, n_shards, nq, k, out_k, (size_t)shard_stride, d_out_ids, d_out_dist, stream);
     });
 }
 

@@ -387,8 +387,12 @@ __device__ __forceinline__ void finish_rows(const WaveCtx& w, uint32_t m, uint32
     float res = acc;
     if (!SCALAR) {
         // lane sums 0..3 of a row sit in 4 adjacent lanes: ((s0 + s1) + s2) + s3
-        const int q0 = w.lane & ~3;
-        const float a0 = __shfl(acc, q0), a1 = __shfl(acc, q0 + 1), a2 = __shfl(acc, q0 + 2), a3 = __shfl(acc, q0 + 3);
+        // (quad broadcasts by DPP: no LDS round trip)
+        const int ai = (int)__float_as_uint(acc);
+        const float a0 = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, ai, 0x00, 0xF, 0xF, false));
+        const float a1 = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, ai, 0x55, 0xF, 0xF, false));
+        const float a2 = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, ai, 0xAA, 0xF, 0xF, false));
+        const float a3 = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, ai, 0xFF, 0xF, 0xF, false));
         res = ((a0 + a1) + a2) + a3;
     }
     if (cj == 0 && b0 + cr < m) w.nb_dist[b0 + cr] = res;

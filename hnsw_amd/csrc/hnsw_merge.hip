@@ -19,6 +19,7 @@ struct MergeArgs {
     const uint32_t* ids;     // S x nq x k, local to the shard; 0xFFFFFFFF = padding
     uint32_t offset[kMaxShards];   // first global id of each shard
     uint32_t S, nq, k, out_k;
+    size_t shard_stride;     // elements between consecutive shards' blocks (>= nq*k)
     uint32_t* out_ids;       // nq x out_k
     float* out_dist;
 };
@@ -33,7 +34,7 @@ __global__ __launch_bounds__(64) void merge_topk_kernel(MergeArgs a)
     const uint32_t total = a.S * a.k;
     for (uint32_t i = lane; i < total; i += 64) {
         const uint32_t s = i / a.k, j = i - s * a.k;
-        const size_t at = ((size_t)s * a.nq + q) * a.k + j;
+        const size_t at = (size_t)s * a.shard_stride + (size_t)q * a.k + j;
         const uint32_t id = a.ids[at];
         const float d = a.dist[at];
         // padding sorts last; distances are non-negative, so their bit patterns order like the floats
@@ -61,13 +62,15 @@ __global__ __launch_bounds__(64) void merge_topk_kernel(MergeArgs a)
 }  // namespace
 
 void merge_topk(const float* d_dist, const uint32_t* d_ids, const uint32_t* shard_offset, uint32_t S, uint32_t nq, uint32_t k,
-                uint32_t out_k, uint32_t* d_out_ids, float* d_out_dist, void* stream)
+                uint32_t out_k, size_t shard_stride, uint32_t* d_out_ids, float* d_out_dist, void* stream)
 {
+    if (shard_stride == 0) shard_stride = (size_t)nq * k;
+    if (shard_stride < (size_t)nq * k) throw std::invalid_argument("merge_topk: shard_stride smaller than one block");
     if (S < 1 || S > (uint32_t)kMaxShards) throw std::invalid_argument("merge_topk: 1..64 shards");
     if (k < 1 || out_k < 1 || (size_t)S * k > 8192) throw std::invalid_argument("merge_topk: S*k must be 1..8192");
     if (nq == 0) return;
     MergeArgs a{};
-    a.dist = d_dist; a.ids = d_ids; a.S = S; a.nq = nq; a.k = k; a.out_k = out_k; a.out_ids = d_out_ids; a.out_dist = d_out_dist;
+    a.dist = d_dist; a.ids = d_ids; a.S = S; a.nq = nq; a.k = k; a.out_k = out_k; a.out_ids = d_out_ids; a.out_dist = d_out_dist; a.shard_stride = shard_stride;
     for (uint32_t s = 0; s < S; s++) a.offset[s] = shard_offset[s];
     hipLaunchKernelGGL(merge_topk_kernel, dim3(nq), dim3(64), (size_t)S * k * sizeof(uint2), (hipStream_t)stream, a);
     hipError_t e = hipGetLastError();

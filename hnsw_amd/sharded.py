@@ -73,23 +73,25 @@ class ShardedHNSW:
         import torch.distributed as dist
 
         nq = q_t.shape[0]
+        # local result: one buffer [2, nq, k] of 32-bit words (distances, then ids), so the exchange is ONE all-gather
+        loc = torch.empty((2, nq, k), dtype=torch.int32, device=q_t.device)
+        loc_d, loc_i = loc[0].view(torch.float32), loc[1]
         if local_search is None:
-            loc_i = torch.empty((nq, k), dtype=torch.int32, device=q_t.device)
-            loc_d = torch.empty((nq, k), dtype=torch.float32, device=q_t.device)
             self.index.search_batch_device(q_t.data_ptr(), nq, ef, k, loc_i.data_ptr(), loc_d.data_ptr(), 0, 0,
                                            torch.cuda.current_stream().cuda_stream)
         else:
-            loc_i, loc_d = local_search(q_t, ef, k)
+            li, ld = local_search(q_t, ef, k)
+            loc_i.copy_(li); loc_d.copy_(ld)
         if self.world == 1:
             return loc_i, loc_d
-        g_i = torch.empty((self.world, nq, k), dtype=torch.int32, device=q_t.device)
-        g_d = torch.empty((self.world, nq, k), dtype=torch.float32, device=q_t.device)
-        dist.all_gather_into_tensor(g_i.view(-1), loc_i.reshape(-1), group=self.group)
-        dist.all_gather_into_tensor(g_d.view(-1), loc_d.reshape(-1), group=self.group)
+        gathered = torch.empty((self.world, 2, nq, k), dtype=torch.int32, device=q_t.device)
+        dist.all_gather_into_tensor(gathered.view(-1), loc.view(-1), group=self.group)
         if merge is not None:
-            return merge(g_d, g_i, self.offsets, k)
+            return merge(gathered[:, 0].view(torch.float32).contiguous(), gathered[:, 1].contiguous(), self.offsets, k)
         out_i = torch.empty((nq, k), dtype=torch.int32, device=q_t.device)
         out_d = torch.empty((nq, k), dtype=torch.float32, device=q_t.device)
-        capi.check(capi.lib().hnsw_amd_merge_topk_device(g_d.data_ptr(), g_i.data_ptr(), capi.u32(self.offsets), self.world, nq, k, k,
-                                                         out_i.data_ptr(), out_d.data_ptr(), torch.cuda.current_stream().cuda_stream))
+        stride = 2 * nq * k
+        capi.check(capi.lib().hnsw_amd_merge_topk_device(gathered.data_ptr(), gathered.data_ptr() + 4 * nq * k, capi.u32(self.offsets),
+                                                         self.world, nq, k, k, stride, out_i.data_ptr(), out_d.data_ptr(),
+                                                         torch.cuda.current_stream().cuda_stream))
         return out_i, out_d

@@ -157,11 +157,14 @@ int hnsw_amd_bruteforce_knn_device(const float* d_base, uint32_t n, const float*
 /* Sharded multi-GPU search, combine step (no counterpart in the reference, which is one
  * in-memory index): d_dist / d_ids hold n_shards per-shard result blocks of nq x k each
  * (ids local to the shard, 0xFFFFFFFF = padding), as an all-gather leaves them;
- * shard_offset[s] (host array) is the global id of shard s's first vector.  Writes the
+ * shard_offset[s] (host array) is the global id of shard s's first vector; shard s's block
+ * starts shard_stride elements after shard s-1's (0 = nq*k, i.e. blocks back to back; a
+ * larger stride lets distances and ids travel in one gathered buffer).  Writes the
  * out_k nearest of each query's n_shards*k candidates (global ids, ascending distance,
  * ties by id) on the current device, asynchronously on `stream`. */
 int hnsw_amd_merge_topk_device(const float* d_dist, const uint32_t* d_ids, const uint32_t* shard_offset, uint32_t n_shards,
-                               uint32_t nq, uint32_t k, uint32_t out_k, uint32_t* d_out_ids, float* d_out_dist, void* stream);
+                               uint32_t nq, uint32_t k, uint32_t out_k, uint64_t shard_stride, uint32_t* d_out_ids, float* d_out_dist,
+                               void* stream);
 
 /* Public data members of the reference object that callers read (src/hnsw.h:221-236). */
 int hnsw_amd_get_info(hnsw_amd_index* h, int32_t* M, int32_t* Mmax, int32_t* Mmax0, int32_t* efConstruction,

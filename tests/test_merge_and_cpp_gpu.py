@@ -27,7 +27,7 @@ def test_merge_kernel_matches_host_merge(S, nq, k):
     i_t = torch.from_numpy(ids.view(np.int32)).cuda()
     o_i = torch.empty((nq, k), dtype=torch.int32, device="cuda")
     o_d = torch.empty((nq, k), dtype=torch.float32, device="cuda")
-    capi.check(capi.lib().hnsw_amd_merge_topk_device(d_t.data_ptr(), i_t.data_ptr(), capi.u32(offsets), S, nq, k, k,
+    capi.check(capi.lib().hnsw_amd_merge_topk_device(d_t.data_ptr(), i_t.data_ptr(), capi.u32(offsets), S, nq, k, k, 0,
                                                      o_i.data_ptr(), o_d.data_ptr(), torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
     assert np.array_equal(o_d.cpu().numpy(), ed)

@@ -35,7 +35,7 @@ def test_sharded_search_and_device_merge(S):
         exp_i.append(oi); exp_d.append(od)
     o_i = torch.empty((nq, k), dtype=torch.int32, device="cuda")
     o_d = torch.empty((nq, k), dtype=torch.float32, device="cuda")
-    capi.check(capi.lib().hnsw_amd_merge_topk_device(g_d.data_ptr(), g_i.data_ptr(), capi.u32(offs), S, nq, k, k, o_i.data_ptr(),
+    capi.check(capi.lib().hnsw_amd_merge_topk_device(g_d.data_ptr(), g_i.data_ptr(), capi.u32(offs), S, nq, k, k, 0, o_i.data_ptr(),
                                                      o_d.data_ptr(), torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
     eg, ed = merge_topk_numpy(np.stack(exp_d), np.stack(exp_i), offs, k)
