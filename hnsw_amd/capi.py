@@ -6,7 +6,9 @@ no fallback: a missing library raises.
 from __future__ import annotations
 
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 import numpy as np
 
@@ -70,11 +72,32 @@ class HnswAmdError(RuntimeError):
         self.code = code
 
 
+def _share_hip_runtime_with_torch() -> None:
+    """A PyTorch-ROCm wheel ships its own libamdhip64.so and loads it by path.  If this
+    library were loaded first it would bind the system copy of the same soname, the process
+    would then hold two HIP runtimes, and whichever initialises second finds no device.
+    Mapping torch's copy first (when a torch install is present; torch itself is not imported)
+    makes the dynamic linker resolve this library's libamdhip64 dependency to that one copy,
+    whatever the import order.  Without torch the system runtime is used."""
+    if "torch" in sys.modules:
+        return                          # torch's runtime is already mapped
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def lib():
     global _LIB
     if _LIB is None:
         if not os.path.exists(LIB_PATH):  # the message below is part of the contract: tests look for it
             raise ImportError(f"{LIB_PATH} is missing: build it with `python -m hnsw_amd.build` (there is no CPU fallback)")
+        _share_hip_runtime_with_torch()
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)       # AttributeError if the library does not export it

@@ -56,3 +56,17 @@ def test_product_package_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
                 assert "liboracle" not in text, f
+
+
+def test_one_hip_runtime_whatever_the_import_order():
+    """PyTorch-ROCm ships its own libamdhip64; loading this library first must not bring a second
+    copy into the process (two runtimes: the one that initialises second finds no device)."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "%s\n"
+            "print(len({l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l}))\n")
+    for order in ("from hnsw_amd import capi; capi.lib(); import torch",
+                  "import torch; from hnsw_amd import capi; capi.lib()"):
+        out = subprocess.run([sys.executable, "-c", code % (ROOT, order)], capture_output=True, text=True)
+        assert out.stdout.strip() == "1", (order, out.stdout, out.stderr[-500:])
