@@ -39,9 +39,6 @@ namespace hnsw_amd {
 namespace {
 
 constexpr uint32_t kEmpty = 0xFFFFFFFFu;
-constexpr int kTileStride = 68;            // dwords per row of the transposition tile (64 + 4: conflict-free chain reads)
-constexpr int kTileDwords = 16 * kTileStride;
-constexpr int kSeg = 64;                   // floats per segment (16 lanes x float4)
 
 __device__ __forceinline__ int32_t trunc_key(float f)
 {
@@ -178,6 +175,18 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t x)
     return __builtin_amdgcn_readlane(x, 63);
 }
 
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t x)
+{
+    uint32_t y;
+    y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0xB1, 0xF, 0xF, false); x = x < y ? x : y;
+    y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x4E, 0xF, 0xF, false); x = x < y ? x : y;
+    y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x141, 0xF, 0xF, false); x = x < y ? x : y;
+    y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x140, 0xF, 0xF, false); x = x < y ? x : y;
+    y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x142, 0xA, 0xF, false); x = x < y ? x : y;
+    y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x143, 0xC, 0xF, false); x = x < y ? x : y;
+    return __builtin_amdgcn_readlane(x, 63);
+}
+
 constexpr uint32_t kWaveHeapMax = 513;   // larger heaps use the one-lane routines
 
 template <class Ord>
@@ -266,178 +275,169 @@ __device__ __forceinline__ bool visited_insert(uint32_t* hash, uint32_t mask, ui
 #define DIAG_ADD(acc, a, b)
 #endif
 
-struct WaveCtx {
-    float* tile;          // kTileDwords
-    float* qs;            // qpad floats, zero padded
-    uint32_t* nb_id;      // 64
-    float* nb_dist;       // 64
-    uint32_t* nb_slot;    // 64
-    const float* vectors;
-    uint32_t row_stride;
-    uint32_t table_bytes; // size of the vector table if it is below 4 GiB (32-bit offsets), else 0
-    uint32_t d_eff;       // dims the distance uses
-    uint32_t nseg;        // ceil(d_eff / 64)
-    uint32_t d4;          // scalar mode: dims whose square is rounded before the add
-    int lane;
+// How the 64 lanes share the rows of one batch of neighbours.
+//  SCALAR=false (the reference's SSE loop, src/hnsw.h:334-383): the 4 lane sums of a row are 4
+//    independent sequential fused-multiply-add chains over the row's 16-byte chunks in index
+//    order.  Two lanes per row: lane p of the pair takes the 8 bytes of every chunk that feed
+//    sums 2p and 2p+1, so each lane runs two chains and nothing is exchanged until the final
+//    ((s0+s1)+s2)+s3.  32 rows per batch.
+//  SCALAR=true (the -DNO_MANUAL_VECTORIZATION build, src/hnsw.h:387-400): one running sum per
+//    row, so one lane per row reads whole 16-byte chunks.  64 rows per batch.
+// One load instruction therefore reads 16 bytes of each row of the batch; the 8 instructions
+// that touch one 128-byte line are adjacent in the instruction stream and merge in the
+// vector L1, and all loads of two groups of chunks are in flight before the first is used.
+template <bool SCALAR>
+struct RowMap {
+    static constexpr int kLanesPerRow = SCALAR ? 1 : 2;
+    static constexpr int kRowsPerBatch = 64 / kLanesPerRow;
+    static constexpr int kGroupChunks = SCALAR ? 8 : 16;      // 16-byte chunks per group (32 registers per lane)
+    static constexpr int kGroupFloats = kGroupChunks * 4;     // dims per group
+};
+
+struct DistCtx {
+    const float* qs;        // query in LDS, zero padded
+    uint32_t nfull;         // groups of chunks processed without per-chunk tests
+    uint32_t ngroups;       // nfull (+1 when tail_chunks > 0)
+    uint32_t tail_chunks;   // chunks of the last, partial group
+    uint32_t d4;            // scalar mode: dims whose square is rounded before the add
 #ifdef HNSW_DIAG
-    mutable uint32_t cy_load = 0, cy_chain = 0, cy_fin = 0;
+    mutable uint32_t cy_load = 0, cy_chain = 0;
 #endif
 };
 
-struct RowRegs { float4 r[4][2]; };    // one lane's share of 16 rows x 2 segments (128 dims)
-
-// Issue the loads of rows nb_id[b0 .. b0+16) for segments s0, s0+1: lane (h, c) takes the
-// 16-byte chunk c of row 4g+h for g = 0..3, so one instruction reads 256 contiguous bytes of
-// each of 4 rows.
-__device__ __forceinline__ void load_rows(const WaveCtx& w, uint32_t m, uint32_t b0, uint32_t s0, RowRegs& R)
-{
-    const int h = w.lane >> 4, c = w.lane & 15;
-    if (w.table_bytes != 0) {
-        // The whole table is addressable with a 32-bit byte offset: buffer loads.  A lane with
-        // nothing to fetch (row index past m, chunk past the used dims) gets an offset beyond
-        // the table; the hardware range check returns zeros for it without touching memory,
-        // so there is no branching around the loads.
-        typedef unsigned u4v __attribute__((ext_vector_type(4)));
-        const __amdgpu_buffer_rsrc_t rsrc =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(w.vectors), 0, (int)w.table_bytes, 0x00020000);
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-            const uint32_t r = b0 + 4 * g + h;
-            const uint32_t id = w.nb_id[r & 63u];
-            const uint32_t row_off = id * (w.row_stride * 4u) + (uint32_t)c * 16u;
-#pragma unroll
-            for (int s = 0; s < 2; s++) {
-                const uint32_t e0 = (s0 + s) * kSeg + c * 4;
-                const uint32_t off = (r < m && e0 < w.d_eff) ? row_off + (s0 + s) * (kSeg * 4u) : 0xFFFFFFFFu;
-                const u4v v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off, 0, 0);
-                R.r[g][s] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-            }
-        }
-        return;
-    }
-#pragma unroll
-    for (int g = 0; g < 4; g++) {
-        const uint32_t r = b0 + 4 * g + h;
-        const bool ok = r < m;
-        const uint32_t id = ok ? w.nb_id[r] : 0u;
-        const float* rp = w.vectors + (size_t)id * w.row_stride + c * 4;
-#pragma unroll
-        for (int s = 0; s < 2; s++) {
-            const uint32_t e0 = (s0 + s) * kSeg + c * 4;
-            R.r[g][s] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok && e0 < w.d_eff) R.r[g][s] = *reinterpret_cast<const float4*>(rp + (s0 + s) * kSeg);
-        }
-    }
-}
-
-// Differences to the query -> transposition tile -> the per-(row, lane-sum) chains, for the
-// segments s0, s0+1 held in R.  Returns the running sum of this lane's chain.
-// SCALAR=false: the reference's SSE loop order (4 lane sums, fma, left-to-right final add).
-// SCALAR=true : the reference's scalar loop as its -DNO_MANUAL_VECTORIZATION build runs it:
-//               one running sum; squares rounded before the add for the first 4*(d/4)
-//               dims, fused multiply-add for the last d%4.
 template <bool SCALAR>
-__device__ __forceinline__ float chain_rows(const WaveCtx& w, uint32_t s0, const RowRegs& R, float acc)
+__device__ __forceinline__ DistCtx make_dist_ctx(const float* qs, uint32_t d)
 {
-    const int h = w.lane >> 4, c = w.lane & 15;     // loader role
-    const int cr = w.lane >> 2, cj = w.lane & 3;    // chain role: row cr of the batch, lane-sum cj
-#pragma unroll
-    for (int s = 0; s < 2; s++) {
-        if (s0 + s < w.nseg) {
-            const uint32_t seg = s0 + s;
-            const uint32_t e0 = seg * kSeg + c * 4;
-            const float4 qv = *reinterpret_cast<const float4*>(w.qs + e0);
-#pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const float4 v = R.r[g][s];
-                float4 t;
-                t.x = v.x - qv.x; t.y = v.y - qv.y; t.z = v.z - qv.z; t.w = v.w - qv.w;
-                if (SCALAR && e0 < w.d4) { t.x = t.x * t.x; t.y = t.y * t.y; t.z = t.z * t.z; t.w = t.w * t.w; }
-                *reinterpret_cast<float4*>(w.tile + (4 * g + h) * kTileStride + c * 4) = t;
-            }
-            LDS_SYNC();
-            const uint32_t left = w.d_eff - seg * kSeg;          // dims of this segment
-            if (!SCALAR) {
-                const uint32_t steps = left >= kSeg ? 16u : (left >> 2);
-                const float* tp = w.tile + cr * kTileStride + cj;
-                if (steps == 16) {
-#pragma unroll
-                    for (int t = 0; t < 16; t++) { float x = tp[4 * t]; acc = __builtin_fmaf(x, x, acc); }
-                } else {
-                    for (uint32_t t = 0; t < steps; t++) { float x = tp[4 * t]; acc = __builtin_fmaf(x, x, acc); }
-                }
-            } else if (cj == 0) {
-                const uint32_t steps = left >= kSeg ? (uint32_t)kSeg : left;
-                const float* tp = w.tile + cr * kTileStride;
-                for (uint32_t t = 0; t < steps; t++) {
-                    float x = tp[t];
-                    if (seg * kSeg + t < w.d4) acc = acc + x; else acc = __builtin_fmaf(x, x, acc);
-                }
-            }
-            LDS_SYNC();
-        }
-    }
-    return acc;
-}
-
-template <bool SCALAR>
-__device__ __forceinline__ void finish_rows(const WaveCtx& w, uint32_t m, uint32_t b0, float acc)
-{
-    const int cr = w.lane >> 2, cj = w.lane & 3;
-    float res = acc;
-    if (!SCALAR) {
-        // lane sums 0..3 of a row sit in 4 adjacent lanes: ((s0 + s1) + s2) + s3
-        // (quad broadcasts by DPP: no LDS round trip)
-        const int ai = (int)__float_as_uint(acc);
-        const float a0 = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, ai, 0x00, 0xF, 0xF, false));
-        const float a1 = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, ai, 0x55, 0xF, 0xF, false));
-        const float a2 = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, ai, 0xAA, 0xF, 0xF, false));
-        const float a3 = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, ai, 0xFF, 0xF, 0xF, false));
-        res = ((a0 + a1) + a2) + a3;
-    }
-    if (cj == 0 && b0 + cr < m) w.nb_dist[b0 + cr] = res;
-}
-
-// Distances from the query to the rows nb_id[0..m) -> nb_dist[0..m).  m <= 64, wave-uniform.
-// Rows of up to 128 used dims: the loads of 32 rows (a whole layer-0 list at M=16) are in
-// flight together before the first is consumed.  Wider rows go 16 rows x 128 dims at a time.
-template <bool SCALAR>
-__device__ __forceinline__ void compute_distances(const WaveCtx& w, uint32_t m)
-{
-    if (w.nseg <= 2) {
-        for (uint32_t b0 = 0; b0 < m; b0 += 32) {
-            RowRegs A, B;
-            DIAG_STAMP(d0);
-            load_rows(w, m, b0, 0, A);
-            const bool two = b0 + 16 < m;
-            if (two) load_rows(w, m, b0 + 16, 0, B);
-#ifdef HNSW_DIAG
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-            DIAG_STAMP(d1);
-            DIAG_ADD(w.cy_load, d0, d1);
-            float accA = chain_rows<SCALAR>(w, 0, A, 0.0f);
-            float accB = 0.0f;
-            if (two) accB = chain_rows<SCALAR>(w, 0, B, 0.0f);
-            DIAG_STAMP(d2);
-            DIAG_ADD(w.cy_chain, d1, d2);
-            finish_rows<SCALAR>(w, m, b0, accA);
-            if (two) finish_rows<SCALAR>(w, m, b0 + 16, accB);
-            DIAG_STAMP(d3);
-            DIAG_ADD(w.cy_fin, d2, d3);
-        }
+    DistCtx c;
+    c.qs = qs;
+    c.d4 = d & ~3u;
+    if (SCALAR) {
+        // every dim takes part; only the groups entirely below d4 are free of the fma tail
+        const uint32_t chunks = (d + 3u) >> 2;
+        c.nfull = c.d4 / RowMap<true>::kGroupFloats;
+        c.tail_chunks = chunks - c.nfull * RowMap<true>::kGroupChunks;
     } else {
-        for (uint32_t b0 = 0; b0 < m; b0 += 16) {
-            float acc = 0.0f;
-            for (uint32_t s0 = 0; s0 < w.nseg; s0 += 2) {
-                RowRegs A;
-                load_rows(w, m, b0, s0, A);
-                acc = chain_rows<SCALAR>(w, s0, A, acc);
+        const uint32_t d_eff = d & ~15u;          // the SSE loop drops the last d mod 16 dims
+        c.nfull = d_eff / RowMap<false>::kGroupFloats;
+        c.tail_chunks = (d_eff % RowMap<false>::kGroupFloats) >> 2;
+    }
+    c.ngroups = c.nfull + (c.tail_chunks ? 1u : 0u);
+    return c;
+}
+
+// SSE order: this lane's 8 bytes of every chunk.
+template <bool FULL>
+__device__ __forceinline__ void issue_group(const float* rp, uint32_t nch, float2 (&v)[16])
+{
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        if (FULL || (uint32_t)k < nch) v[k] = *reinterpret_cast<const float2*>(rp + 4 * k);
+}
+
+template <bool FULL>
+__device__ __forceinline__ void consume_group(const float* qp, uint32_t nch, const float2 (&v)[16], float& a0, float& a1)
+{
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        if (FULL || (uint32_t)k < nch) {
+            const float2 q = *reinterpret_cast<const float2*>(qp + 4 * k);
+            const float t0 = v[k].x - q.x, t1 = v[k].y - q.y;
+            a0 = __builtin_fmaf(t0, t0, a0);
+            a1 = __builtin_fmaf(t1, t1, a1);
+        }
+}
+
+// Scalar order: whole chunks, one running sum; squares are rounded before the add for the
+// first 4*(d/4) dims and fused for the last d%4 (what g++ 11 emits for that loop).
+template <bool FULL>
+__device__ __forceinline__ void issue_group(const float* rp, uint32_t nch, float4 (&v)[8])
+{
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+        if (FULL || (uint32_t)k < nch) v[k] = *reinterpret_cast<const float4*>(rp + 4 * k);
+}
+
+template <bool FULL>
+__device__ __forceinline__ void consume_group(const float* qp, uint32_t nch, uint32_t e0, uint32_t d4, const float4 (&v)[8], float& a)
+{
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+        if (FULL || (uint32_t)k < nch) {
+            const float4 q = *reinterpret_cast<const float4*>(qp + 4 * k);
+            const float t0 = v[k].x - q.x, t1 = v[k].y - q.y, t2 = v[k].z - q.z, t3 = v[k].w - q.w;
+            if (FULL || e0 + 4 * k < d4) {
+                const float s0 = t0 * t0, s1 = t1 * t1, s2 = t2 * t2, s3 = t3 * t3;
+                a = a + s0; a = a + s1; a = a + s2; a = a + s3;
+            } else {
+                a = __builtin_fmaf(t0, t0, a); a = __builtin_fmaf(t1, t1, a);
+                a = __builtin_fmaf(t2, t2, a); a = __builtin_fmaf(t3, t3, a);
             }
-            finish_rows<SCALAR>(w, m, b0, acc);
+        }
+}
+
+// Distance from the query to the row `row` points at, for the lanes with `active` set; the
+// result is valid in the first lane of every row's lane group.  Called by all 64 lanes.
+template <bool SCALAR>
+__device__ __forceinline__ float row_distance(const DistCtx& c, const float* row, bool active, int lane)
+{
+    typedef RowMap<SCALAR> RM;
+    float a0 = 0.0f, a1 = 0.0f;
+    DIAG_STAMP(d0);
+    if (active) {
+        const uint32_t ng = c.ngroups, nf = c.nfull, tc = c.tail_chunks;
+        if (SCALAR) {
+            float4 A[8], B[8];
+            const float* qs = c.qs;
+            if (0 < nf) issue_group<true>(row, 0, A); else issue_group<false>(row, tc, A);
+            if (ng > 1) { if (1 < nf) issue_group<true>(row + RM::kGroupFloats, 0, B); else issue_group<false>(row + RM::kGroupFloats, tc, B); }
+            for (uint32_t g = 0; g < ng; g += 2) {
+                if (g < nf) consume_group<true>(qs + g * RM::kGroupFloats, 0, 0, 0, A, a0);
+                else consume_group<false>(qs + g * RM::kGroupFloats, tc, g * RM::kGroupFloats, c.d4, A, a0);
+                if (g + 2 < ng) {
+                    if (g + 2 < nf) issue_group<true>(row + (g + 2) * RM::kGroupFloats, 0, A);
+                    else issue_group<false>(row + (g + 2) * RM::kGroupFloats, tc, A);
+                }
+                if (g + 1 < ng) {
+                    if (g + 1 < nf) consume_group<true>(qs + (g + 1) * RM::kGroupFloats, 0, 0, 0, B, a0);
+                    else consume_group<false>(qs + (g + 1) * RM::kGroupFloats, tc, (g + 1) * RM::kGroupFloats, c.d4, B, a0);
+                    if (g + 3 < ng) {
+                        if (g + 3 < nf) issue_group<true>(row + (g + 3) * RM::kGroupFloats, 0, B);
+                        else issue_group<false>(row + (g + 3) * RM::kGroupFloats, tc, B);
+                    }
+                }
+            }
+        } else {
+            float2 A[16], B[16];
+            const int p = lane & 1;
+            const float* rp = row + 2 * p;
+            const float* qs = c.qs + 2 * p;
+            if (0 < nf) issue_group<true>(rp, 0, A); else issue_group<false>(rp, tc, A);
+            if (ng > 1) { if (1 < nf) issue_group<true>(rp + RM::kGroupFloats, 0, B); else issue_group<false>(rp + RM::kGroupFloats, tc, B); }
+            for (uint32_t g = 0; g < ng; g += 2) {
+                if (g < nf) consume_group<true>(qs + g * RM::kGroupFloats, 0, A, a0, a1);
+                else consume_group<false>(qs + g * RM::kGroupFloats, tc, A, a0, a1);
+                if (g + 2 < ng) {
+                    if (g + 2 < nf) issue_group<true>(rp + (g + 2) * RM::kGroupFloats, 0, A);
+                    else issue_group<false>(rp + (g + 2) * RM::kGroupFloats, tc, A);
+                }
+                if (g + 1 < ng) {
+                    if (g + 1 < nf) consume_group<true>(qs + (g + 1) * RM::kGroupFloats, 0, B, a0, a1);
+                    else consume_group<false>(qs + (g + 1) * RM::kGroupFloats, tc, B, a0, a1);
+                    if (g + 3 < ng) {
+                        if (g + 3 < nf) issue_group<true>(rp + (g + 3) * RM::kGroupFloats, 0, B);
+                        else issue_group<false>(rp + (g + 3) * RM::kGroupFloats, tc, B);
+                    }
+                }
+            }
         }
     }
-    LDS_SYNC();
+    DIAG_STAMP(d1);
+    DIAG_ADD(c.cy_chain, d0, d1);
+    if (SCALAR) return a0;
+    // sums 0,1 are in the even lane of the pair, sums 2,3 in the odd one: ((s0 + s1) + s2) + s3
+    const float s2 = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(a0), 0xF5, 0xF, 0xF, false));   // quad_perm [1,1,3,3]
+    const float s3 = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(a1), 0xF5, 0xF, 0xF, false));
+    return ((a0 + a1) + s2) + s3;
 }
 
 // WR = 0: the result list W is the libstdc++ max-heap in LDS, maintained exactly as the
@@ -450,39 +450,32 @@ __device__ __forceinline__ void compute_distances(const WaveCtx& w, uint32_t m)
 template <bool SCALAR, int WR>
 __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
 {
+    typedef RowMap<SCALAR> RM;
     extern __shared__ __align__(16) uint32_t smem[];
     const int lane = threadIdx.x;
+    const uint32_t r = (uint32_t)lane / RM::kLanesPerRow;              // row of the batch this lane works on
+    const bool owner = (lane % RM::kLanesPerRow) == 0;                // the lane that holds the row's id and distance
     uint32_t qi = blockIdx.x;
     if (a.qmap) qi = a.qmap[qi];
 
-    WaveCtx w;
-    w.tile = reinterpret_cast<float*>(smem);
-    w.qs = w.tile + kTileDwords;
-    w.nb_id = smem + kTileDwords + a.qpad;
-    w.nb_dist = reinterpret_cast<float*>(w.nb_id + 64);
-    w.nb_slot = w.nb_id + 128;
-    // W in LDS: the exact-heap mode keeps it there throughout; the register mode only needs it
-    // for the final sort, after the last use of the tile, so it shares the tile's space
-    uint2* W = WR == 0 ? reinterpret_cast<uint2*>(w.nb_id + 192) : reinterpret_cast<uint2*>(smem);
-    uint2* C = reinterpret_cast<uint2*>(w.nb_id + 192) + (WR == 0 ? a.cap_w : 0u);
+    // LDS: query | W (exact-heap mode only) | C | visited.  The register mode needs W in LDS only for the
+    // final sort, when C is dead, so it borrows C's space.
+    float* qs = reinterpret_cast<float*>(smem);
+    uint2* W = reinterpret_cast<uint2*>(smem + a.qpad);
+    uint2* C = W + (WR == 0 ? a.cap_w : 0u);
     uint32_t* hash = reinterpret_cast<uint32_t*>(C + a.cap_c);
     const uint32_t H = 1u << a.hash_bits, hmask = H - 1, hshift = 32 - a.hash_bits;
     const uint32_t visit_limit = H - (H >> 3);       // keep the table at most 7/8 full
-    w.vectors = a.g.vectors; w.row_stride = a.g.row_stride; w.lane = lane;
-    {
-        const unsigned long long tb = (unsigned long long)a.g.n * a.g.row_stride * 4ull;
-        w.table_bytes = tb < 0xFFFFFFF0ull ? (uint32_t)tb : 0u;
-    }
-    w.d_eff = SCALAR ? a.g.d : (a.g.d & ~15u);
-    w.nseg = (w.d_eff + kSeg - 1) / kSeg;
-    w.d4 = a.g.d & ~3u;
+    const float* const vectors = a.g.vectors;
+    const uint32_t row_stride = a.g.row_stride;
+    const DistCtx dc = make_dist_ctx<SCALAR>(qs, a.g.d);
     const bool float_keys = (a.flags & HNSW_AMD_KEYS_FLOAT) != 0;
     const uint32_t ef = a.ef;
 
     // query into LDS (zero padded), visited set empty
     {
         const float* q = a.queries + (size_t)qi * a.g.d;
-        for (uint32_t i = lane; i < a.qpad; i += 64) w.qs[i] = i < a.g.d ? q[i] : 0.0f;
+        for (uint32_t i = lane; i < a.qpad; i += 64) qs[i] = i < a.g.d ? q[i] : 0.0f;
         for (uint32_t i = lane; i < H; i += 64) hash[i] = kEmpty;
     }
     LDS_SYNC();
@@ -498,10 +491,11 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
     const int L = (int)a.g.nlayers - 1;
     uint32_t cur_slot = a.g.top_ep_slot, cur_id = a.g.top_ep_order;
     float cur_dist;
-    if (lane == 0) { w.nb_id[0] = cur_id; visited_insert(hash, hmask, hshift, cur_id); }
-    LDS_SYNC();
-    compute_distances<SCALAR>(w, 1);
-    cur_dist = w.nb_dist[0];
+    if (lane == 0) visited_insert(hash, hmask, hshift, cur_id);
+    {
+        const float dj = row_distance<SCALAR>(dc, vectors + (size_t)cur_id * row_stride, r == 0, lane);
+        cur_dist = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(dj), 0));
+    }
     st.n_dist = 1;
     uint32_t nvis = 1;
     LDS_SYNC();
@@ -514,36 +508,35 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
         while (change) {
             change = false;
             if (nvis + 64 > visit_limit) { fail = 1; break; }
+            st.n_sweeps++;
+            // The sweep covers the whole list of the node current at its start; the running best moves
+            // only on a strict improvement, i.e. to the first minimum of the list.
             const size_t rowi = (size_t)(base + cur_slot) * a.g.degu;
-            uint32_t my_order = kEmpty, my_slot = kEmpty;
-            if ((uint32_t)lane < a.g.degu) { my_order = a.g.up_adj_order[rowi + lane]; my_slot = a.g.up_adj_slot[rowi + lane]; }
-            const bool live = my_order != kEmpty;
-            const bool fresh = live && visited_insert(hash, hmask, hshift, my_order);
-            const unsigned long long fm = __ballot(fresh);
-            const uint32_t m = (uint32_t)__popcll(fm);
-            const uint32_t rank = (uint32_t)__popcll(fm & ((1ull << lane) - 1ull));
-            if (fresh) { w.nb_id[rank] = my_order; w.nb_slot[rank] = my_slot; }
-            st.n_sweeps++; st.sum_degu += (uint32_t)__popcll(__ballot(live));
-            st.n_dist += m; nvis += m;
-            LDS_SYNC();
-            if (m == 0) continue;
-            compute_distances<SCALAR>(w, m);
-            // first minimum among the new distances, taken only if it improves (strict <)
-            float bd = (uint32_t)lane < m ? w.nb_dist[lane] : __builtin_inff();
-            if (!(bd == bd)) bd = __builtin_inff();
-            uint32_t bj = lane;
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                float od = __shfl_xor(bd, off);
-                uint32_t oj = __shfl_xor(bj, off);
-                if (od < bd || (od == bd && oj < bj)) { bd = od; bj = oj; }
+            for (uint32_t b0 = 0; b0 < a.g.degu; b0 += RM::kRowsPerBatch) {
+                uint32_t my_order = kEmpty, my_slot = kEmpty;
+                if (b0 + r < a.g.degu) { my_order = a.g.up_adj_order[rowi + b0 + r]; my_slot = a.g.up_adj_slot[rowi + b0 + r]; }
+                const bool live = my_order != kEmpty;
+                bool fresh = live && owner && visited_insert(hash, hmask, hshift, my_order);
+                if (RM::kLanesPerRow == 2) fresh = __builtin_amdgcn_update_dpp(0, (int)fresh, 0xA0, 0xF, 0xF, false) != 0;   // quad_perm [0,0,2,2]
+                const uint32_t m = (uint32_t)__popcll(__ballot(fresh && owner));
+                st.sum_degu += (uint32_t)__popcll(__ballot(live && owner));
+                st.n_dist += m; nvis += m;
+                LDS_SYNC();
+                if (m == 0) continue;
+                const float dj = row_distance<SCALAR>(dc, vectors + (size_t)my_order * row_stride, fresh, lane);
+                const bool mine = fresh && owner && dj == dj;
+                const uint32_t key = mine ? __float_as_uint(dj) : 0x7F800000u;     // non-negative floats order as their bit patterns
+                const uint32_t kmin = wave_min_u32(key);
+                const float bd = __uint_as_float(kmin);
+                if (bd < cur_dist) {
+                    const unsigned long long who = __ballot(mine && key == kmin);
+                    const int j = __builtin_ctzll(who);
+                    change = true;
+                    cur_dist = bd;
+                    cur_id = __builtin_amdgcn_readlane(my_order, j);
+                    cur_slot = __builtin_amdgcn_readlane(my_slot, j);
+                }
             }
-            bd = rflf(bd); bj = rfl(bj);
-            if (bd < cur_dist) {
-                change = true;
-                cur_dist = bd; cur_id = w.nb_id[bj]; cur_slot = w.nb_slot[bj];
-            }
-            LDS_SYNC();
         }
         if (!fail) cur_slot = a.g.up_down[base + cur_slot];      // changeLayer, src/hnsw.h:575-587
     }
@@ -565,11 +558,11 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
             visited_insert(hash, hmask, hshift, cur_id);
         }
 #pragma unroll
-        for (int r = 0; r < (WR > 0 ? WR : 1); r++) { wd[r] = 0; wi[r] = 0; }
+        for (int w = 0; w < (WR > 0 ? WR : 1); w++) { wd[w] = 0; wi[w] = 0; }
         if (WR > 0 && lane == 0) { wd[0] = __float_as_uint(cur_dist); wi[0] = cur_id; }
         nW = 1; nC = 1; nvis = 1; f = cur_dist; st.max_c = 1;
         LDS_SYNC();
-        while (nC > 0) {
+        while (nC > 0 && !fail) {
             DIAG_STAMP(t0);
             uint32_t ckey, cid;
             uint32_t my = kEmpty;
@@ -577,7 +570,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
                 const uint2 c = C[0];
                 ckey = rfl(c.x); cid = rfl(c.y);
                 // the candidate's neighbour list is requested now and arrives while the heap is repaired
-                if ((uint32_t)lane < a.g.deg0) my = a.g.adj0[(size_t)cid * a.g.deg0 + lane];
+                if (r < a.g.deg0) my = a.g.adj0[(size_t)cid * a.g.deg0 + r];
                 if (nC > 1) {
                     if (nC <= kWaveHeapMax) heap_pop_wave<COrder>(C, nC, lane);
                     else if (lane == 0) c_pop(C, nC);
@@ -589,94 +582,99 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
             DIAG_ADD(cy_pop, t0, t1);
             if (float_keys) { if (__uint_as_float(ckey) > f) break; }
             else { if ((float)(int32_t)ckey > f) break; }
-            if (nvis + 64 > visit_limit) { fail = 1; break; }
-            const bool live = my != kEmpty;
-            const bool fresh = live && visited_insert(hash, hmask, hshift, my);
-            const unsigned long long fm = __ballot(fresh);
-            const uint32_t m = (uint32_t)__popcll(fm);
-            const uint32_t rank = (uint32_t)__popcll(fm & ((1ull << lane) - 1ull));
-            if (fresh) w.nb_id[rank] = my;
-            st.n_expand++; st.sum_deg0 += (uint32_t)__popcll(__ballot(live));
-            st.n_dist += m; nvis += m;
-            LDS_SYNC();
-            DIAG_STAMP(t2);
-            DIAG_ADD(cy_adj, t1, t2);
-            if (m == 0) continue;
-            compute_distances<SCALAR>(w, m);
-            DIAG_STAMP(t3);
-            DIAG_ADD(cy_dist, t2, t3);
-            // Admission in list order (src/hnsw.cpp:765-777).  A neighbour that fails
-            // `dist < f` against the f at the start of the expansion can only be admitted
-            // while W is not full; f never grows once W is full, so skipping the others is exact.
-            const float dj = (uint32_t)lane < m ? w.nb_dist[lane] : 0.0f;
-            const uint32_t idj = (uint32_t)lane < m ? w.nb_id[lane] : 0u;
-            unsigned long long todo = __ballot((uint32_t)lane < m && (dj < f || nW < ef));
-            if (nC + (uint32_t)__popcll(todo) > a.cap_c) { fail = 2; break; }
-            while (todo) {
-                const int j = __builtin_ctzll(todo);
-                todo &= todo - 1;
-                const float dist = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(dj), j));
-                if (dist < f || nW < ef) {
-                    const uint32_t id = __builtin_amdgcn_readlane(idj, j);
-                    const uint2 ce = make_uint2(float_keys ? __float_as_uint(dist) : (uint32_t)trunc_key(dist), id);
-                    const uint2 we = make_uint2(__float_as_uint(dist), id);
-                    nC++;
-                    if (WR > 0) {
-                        if (nC <= kWaveHeapMax) heap_push_wave<COrder>(C, nC, ce, lane);
-                        else { if (lane == 0) { C[nC - 1] = ce; c_push(C, nC); } }
-                        if (nW < ef) {
-                            // W not full: append; f stays the largest distance in W
+            st.n_expand++;
+            for (uint32_t b0 = 0;;) {
+                DIAG_STAMP(t1b);
+                if (nvis + 64 > visit_limit) { fail = 1; break; }
+                const bool live = my != kEmpty;
+                const uint32_t nlive = (uint32_t)__popcll(__ballot(live && owner));
+                bool fresh = live && owner && visited_insert(hash, hmask, hshift, my);
+                if (RM::kLanesPerRow == 2) fresh = __builtin_amdgcn_update_dpp(0, (int)fresh, 0xA0, 0xF, 0xF, false) != 0;   // quad_perm [0,0,2,2]
+                const uint32_t m = (uint32_t)__popcll(__ballot(fresh && owner));
+                st.sum_deg0 += nlive; st.n_dist += m; nvis += m;
+                LDS_SYNC();
+                DIAG_STAMP(t2);
+                DIAG_ADD(cy_adj, t1b, t2);
+                if (m != 0) {
+                    const float dj = row_distance<SCALAR>(dc, vectors + (size_t)my * row_stride, fresh, lane);
+                    DIAG_STAMP(t3);
+                    DIAG_ADD(cy_dist, t2, t3);
+                    // Admission in list order (src/hnsw.cpp:765-777).  A neighbour that fails
+                    // `dist < f` against the f at the start of the expansion can only be admitted
+                    // while W is not full; f never grows once W is full, so skipping the others is exact.
+                    unsigned long long todo = __ballot(fresh && owner && (dj < f || nW < ef));
+                    if (nC + (uint32_t)__popcll(todo) > a.cap_c) { fail = 2; break; }
+                    while (todo) {
+                        const int j = __builtin_ctzll(todo);
+                        todo &= todo - 1;
+                        const float dist = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(dj), j));
+                        if (dist < f || nW < ef) {
+                            const uint32_t id = __builtin_amdgcn_readlane(my, j);
+                            const uint2 ce = make_uint2(float_keys ? __float_as_uint(dist) : (uint32_t)trunc_key(dist), id);
+                            const uint2 we = make_uint2(__float_as_uint(dist), id);
+                            nC++;
+                            if (WR > 0) {
+                                if (nC <= kWaveHeapMax) heap_push_wave<COrder>(C, nC, ce, lane);
+                                else { if (lane == 0) { C[nC - 1] = ce; c_push(C, nC); } }
+                                if (nW < ef) {
+                                    // W not full: append; f stays the largest distance in W
 #pragma unroll
-                            for (int r = 0; r < WR; r++)
-                                if ((nW >> 6) == (uint32_t)r && (nW & 63u) == (uint32_t)lane) { wd[r] = we.x; wi[r] = we.y; }
-                            nW++;
-                            f = dist > f ? dist : f;
-                        } else {
-                            // W full and dist < f: the new entry replaces one entry at distance f
-                            const uint32_t fb = __float_as_uint(f);
-                            bool done = false;
-                            uint32_t mx = 0;
+                                    for (int w = 0; w < WR; w++)
+                                        if ((nW >> 6) == (uint32_t)w && (nW & 63u) == (uint32_t)lane) { wd[w] = we.x; wi[w] = we.y; }
+                                    nW++;
+                                    f = dist > f ? dist : f;
+                                } else {
+                                    // W full and dist < f: the new entry replaces one entry at distance f
+                                    const uint32_t fb = __float_as_uint(f);
+                                    bool done = false;
+                                    uint32_t mx = 0;
 #pragma unroll
-                            for (int r = 0; r < WR; r++) {
-                                const unsigned long long hit = done ? 0ull : __ballot(wd[r] == fb);
-                                if (hit) { if (lane == __builtin_ctzll(hit)) { wd[r] = we.x; wi[r] = we.y; } done = true; }
-                                mx = wd[r] > mx ? wd[r] : mx;
+                                    for (int w = 0; w < WR; w++) {
+                                        const unsigned long long hit = done ? 0ull : __ballot(wd[w] == fb);
+                                        if (hit) { if (lane == __builtin_ctzll(hit)) { wd[w] = we.x; wi[w] = we.y; } done = true; }
+                                        mx = wd[w] > mx ? wd[w] : mx;
+                                    }
+                                    f = __uint_as_float(wave_max_u32(mx));   // non-negative floats order as their bit patterns
+                                }
+                                LDS_SYNC();
+                            } else {
+                                nW++;
+                                if (nC <= kWaveHeapMax && nW <= kWaveHeapMax) {
+                                    heap_push_wave<COrder>(C, nC, ce, lane);
+                                    heap_push_wave<WOrder>(W, nW, we, lane);
+                                    LDS_SYNC();
+                                    if (nW > ef) {
+                                        const uint2 root = heap_pop_wave<WOrder>(W, nW, lane);
+                                        nW--;
+                                        f = __uint_as_float(root.x);
+                                        LDS_SYNC();
+                                    } else {
+                                        f = __uint_as_float(W[0].x);
+                                    }
+                                } else {
+                                    if (lane == 0) {
+                                        C[nC - 1] = ce; c_push(C, nC);
+                                        W[nW - 1] = we; w_push(W, nW);
+                                        if (nW > ef) w_pop(W, nW);
+                                    }
+                                    if (nW > ef) nW--;
+                                    LDS_SYNC();
+                                    f = __uint_as_float(W[0].x);
+                                }
                             }
-                            f = __uint_as_float(wave_max_u32(mx));   // non-negative floats order as their bit patterns
+                            if (nC > st.max_c) st.max_c = nC;
                         }
-                        LDS_SYNC();
-                    } else {
-                    nW++;
-                    if (nC <= kWaveHeapMax && nW <= kWaveHeapMax) {
-                        heap_push_wave<COrder>(C, nC, ce, lane);
-                        heap_push_wave<WOrder>(W, nW, we, lane);
-                        LDS_SYNC();
-                        if (nW > ef) {
-                            const uint2 root = heap_pop_wave<WOrder>(W, nW, lane);
-                            nW--;
-                            f = __uint_as_float(root.x);
-                            LDS_SYNC();
-                        } else {
-                            f = __uint_as_float(W[0].x);
-                        }
-                    } else {
-                        if (lane == 0) {
-                            C[nC - 1] = ce; c_push(C, nC);
-                            W[nW - 1] = we; w_push(W, nW);
-                            if (nW > ef) w_pop(W, nW);
-                        }
-                        if (nW > ef) nW--;
-                        LDS_SYNC();
-                        f = __uint_as_float(W[0].x);
                     }
-                    }
-                    if (nC > st.max_c) st.max_c = nC;
+                    nW = rfl(nW); nC = rfl(nC); f = rflf(f); st.max_c = rfl(st.max_c);
+                    LDS_SYNC();
+                    DIAG_STAMP(t4);
+                    DIAG_ADD(cy_adm, t3, t4);
                 }
+                // the live entries of a list are a prefix: a batch with a gap was the last one
+                b0 += RM::kRowsPerBatch;
+                if (b0 >= a.g.deg0 || nlive < (uint32_t)RM::kRowsPerBatch) break;
+                my = b0 + r < a.g.deg0 ? a.g.adj0[(size_t)cid * a.g.deg0 + b0 + r] : kEmpty;
             }
-            nW = rfl(nW); nC = rfl(nC); f = rflf(f); st.max_c = rfl(st.max_c);
-            LDS_SYNC();
-            DIAG_STAMP(t4);
-            DIAG_ADD(cy_adm, t3, t4);
         }
     }
     st.n_visited0 = nvis;
@@ -695,8 +693,8 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
     LDS_SYNC();
     if (WR > 0) {
 #pragma unroll
-        for (int r = 0; r < WR; r++)
-            if ((uint32_t)(r * 64 + lane) < nW) W[r * 64 + lane] = make_uint2(wd[r], wi[r]);
+        for (int w = 0; w < WR; w++)
+            if ((uint32_t)(w * 64 + lane) < nW) W[w * 64 + lane] = make_uint2(wd[w], wi[w]);
         LDS_SYNC();
     }
     for (uint32_t i = lane; i < nW; i += 64) {
@@ -720,10 +718,9 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
         DIAG_STAMP(t_end);
         DIAG_ADD(cy_fin, t_l0_end, t_end);
         st.max_c = st.n_expand;
-        st.n_dist = cy_pop; st.n_expand = cy_adj; st.n_sweeps = cy_dist; st.sum_deg0 = cy_adm;
-        st.sum_degu = cy_up; st.n_visited0 = cy_fin; st.n_visited_up = (uint32_t)(t_end - t_begin);
-        // finer split of the distance phase, in place of two of the coarse sums
-        st.n_dist = w.cy_load; st.sum_degu = w.cy_chain; st.n_visited0 = w.cy_fin;
+        st.n_dist = dc.cy_chain; st.n_expand = cy_adj; st.n_sweeps = cy_dist; st.sum_deg0 = cy_adm;
+        st.sum_degu = cy_pop; st.n_visited0 = cy_fin; st.n_visited_up = (uint32_t)(t_end - t_begin);
+        (void)cy_up;
     }
 #endif
     if (lane == 0) {
@@ -736,8 +733,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
 
 size_t search_lds_bytes(const SearchArgs& a, bool w_in_lds)
 {
-    size_t dwords = (size_t)kTileDwords + a.qpad + 192 + (w_in_lds ? 2 * (size_t)a.cap_w : 0) + 2 * (size_t)a.cap_c +
-                    ((size_t)1 << a.hash_bits);
+    size_t dwords = (size_t)a.qpad + (w_in_lds ? 2 * (size_t)a.cap_w : 0) + 2 * (size_t)a.cap_c + ((size_t)1 << a.hash_bits);
     return dwords * 4;
 }
 
@@ -857,7 +853,7 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
         ScratchTier t = tier_for(ef, tier);
         a.hash_bits = t.hash_bits; a.cap_c = t.cap_c;
         const bool std_heap = (flags & HNSW_AMD_W_STD_HEAP) != 0 || ef > 256;
-        if (!std_heap && 2 * (size_t)a.cap_w > (size_t)kTileDwords) throw std::logic_error("search: W does not fit the tile");
+        if (!std_heap && a.cap_w > a.cap_c) throw std::logic_error("search: W does not fit the space it borrows for the final sort");
         size_t lds = search_lds_bytes(a, std_heap);
         if (lds > (size_t)max_lds) {
             throw std::length_error("search: " + std::to_string(a.nq_launch) +
