@@ -19,6 +19,7 @@
 // :725-787 (searchLayer), src/hnsw.h:334-400 (distance), :55-125 (visited set).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <stdexcept>
@@ -275,34 +276,38 @@ __device__ __forceinline__ bool visited_insert(uint32_t* hash, uint32_t mask, ui
 #define DIAG_ADD(acc, a, b)
 #endif
 
-// How the 64 lanes share the rows of one batch of neighbours.
-//  SCALAR=false (the reference's SSE loop, src/hnsw.h:334-383): the 4 lane sums of a row are 4
-//    independent sequential fused-multiply-add chains over the row's 16-byte chunks in index
-//    order.  Two lanes per row: lane p of the pair takes the 8 bytes of every chunk that feed
-//    sums 2p and 2p+1, so each lane runs two chains and nothing is exchanged until the final
-//    ((s0+s1)+s2)+s3.  32 rows per batch.
+// Stored form of a base vector (and of the query copy in LDS): every 128-byte line holds 32
+// consecutive dims, regrouped by the lane sum they feed in the reference's SSE loop
+// (src/hnsw.h:349-380): dim 32*l + 4*k + j (k = 0..7, j = 0..3) sits at float 32*l + 8*j + k.
+// The 8 elements that sum j takes from a line are then 32 contiguous bytes.
+__host__ __device__ __forceinline__ uint32_t stored_pos(uint32_t dim)
+{
+    return (dim & ~31u) | ((dim & 3u) << 3) | ((dim >> 2) & 7u);
+}
+
+// How the 64 lanes share the rows of a neighbour list.
+//  SCALAR=false (the SSE loop): the 4 lane sums of a row are 4 independent sequential fused-multiply-add
+//    chains in index order.  Four lanes per row, lane j runs chain j: it reads its 32 bytes of
+//    every line (2 x 16 B) and nothing is exchanged until the final ((s0+s1)+s2)+s3.  A load
+//    instruction covers 16 rows x 64 bytes, so a line is touched by 2 instructions.  A list is
+//    handled 32 rows at a time as two sub-batches of 16 whose loads are in flight together.
 //  SCALAR=true (the -DNO_MANUAL_VECTORIZATION build, src/hnsw.h:387-400): one running sum per
-//    row, so one lane per row reads whole 16-byte chunks.  64 rows per batch.
-// One load instruction therefore reads 16 bytes of each row of the batch; the 8 instructions
-// that touch one 128-byte line are adjacent in the instruction stream and merge in the
-// vector L1, and all loads of two groups of chunks are in flight before the first is used.
+//    row, so one lane per row reads whole lines; 64 rows per batch.
 template <bool SCALAR>
 struct RowMap {
-    static constexpr int kLanesPerRow = SCALAR ? 1 : 2;
-    static constexpr int kRowsPerBatch = 64 / kLanesPerRow;
-    static constexpr int kGroupChunks = SCALAR ? 8 : 16;      // 16-byte chunks per group (32 registers per lane)
-    static constexpr int kGroupFloats = kGroupChunks * 4;     // dims per group
+    static constexpr int kLanesPerRow = SCALAR ? 1 : 4;
+    static constexpr int kSub = SCALAR ? 1 : 2;                   // sub-batches in flight
+    static constexpr int kRowsPerSub = 64 / kLanesPerRow;
+    static constexpr int kRowsPerBatch = kSub * kRowsPerSub;
+    static constexpr int kItemFloats = SCALAR ? 32 : 128;         // dims one "item" (8 x 16-byte loads per lane) covers
 };
 
 struct DistCtx {
-    const float* qs;        // query in LDS, zero padded
-    uint32_t nfull;         // groups of chunks processed without per-chunk tests
-    uint32_t ngroups;       // nfull (+1 when tail_chunks > 0)
-    uint32_t tail_chunks;   // chunks of the last, partial group
+    const float* qs;        // query in LDS, stored form, zero padded
+    uint32_t nfull;         // items processed without per-load tests
+    uint32_t nitems;        // nfull (+1 when tail_loads > 0)
+    uint32_t tail_loads;    // 16-byte loads per lane of the last, partial item
     uint32_t d4;            // scalar mode: dims whose square is rounded before the add
-#ifdef HNSW_DIAG
-    mutable uint32_t cy_load = 0, cy_chain = 0;
-#endif
 };
 
 template <bool SCALAR>
@@ -312,133 +317,156 @@ __device__ __forceinline__ DistCtx make_dist_ctx(const float* qs, uint32_t d)
     c.qs = qs;
     c.d4 = d & ~3u;
     if (SCALAR) {
-        // every dim takes part; only the groups entirely below d4 are free of the fma tail
-        const uint32_t chunks = (d + 3u) >> 2;
-        c.nfull = c.d4 / RowMap<true>::kGroupFloats;
-        c.tail_chunks = chunks - c.nfull * RowMap<true>::kGroupChunks;
+        // every dim takes part; an item is one line, always loaded whole (rows and query are
+        // zero padded, and adding the square of 0 changes nothing); only lines entirely below
+        // d4 are free of the fused tail
+        const uint32_t lines = (d + 31u) >> 5;
+        c.nfull = c.d4 >> 5;
+        c.tail_loads = lines > c.nfull ? 8u : 0u;
     } else {
         const uint32_t d_eff = d & ~15u;          // the SSE loop drops the last d mod 16 dims
-        c.nfull = d_eff / RowMap<false>::kGroupFloats;
-        c.tail_chunks = (d_eff % RowMap<false>::kGroupFloats) >> 2;
+        c.nfull = d_eff >> 7;
+        c.tail_loads = (d_eff & 127u) >> 4;       // one load per lane = 4 elements of its chain = 16 dims of the row
     }
-    c.ngroups = c.nfull + (c.tail_chunks ? 1u : 0u);
+    c.nitems = c.nfull + (c.tail_loads ? 1u : 0u);
     return c;
 }
 
-// SSE order: this lane's 8 bytes of every chunk.
-template <bool FULL>
-__device__ __forceinline__ void issue_group(const float* rp, uint32_t nch, float2 (&v)[16])
+// SSE mode: the lane's 2 x 16 bytes of each of 4 lines.  Scalar mode: one whole line.
+template <bool SCALAR, bool FULL>
+__device__ __forceinline__ void issue_item(const float* p, uint32_t nld, float4 (&v)[8])
 {
 #pragma unroll
-    for (int k = 0; k < 16; k++)
-        if (FULL || (uint32_t)k < nch) v[k] = *reinterpret_cast<const float2*>(rp + 4 * k);
+    for (int t = 0; t < 8; t++)
+        if (FULL || (uint32_t)t < nld) v[t] = *reinterpret_cast<const float4*>(p + (SCALAR ? 4 * t : 32 * (t >> 1) + 4 * (t & 1)));
 }
 
+// SSE order, lane j of the row's quad: p / qp point at this lane's 8 floats of the item's first line.
 template <bool FULL>
-__device__ __forceinline__ void consume_group(const float* qp, uint32_t nch, const float2 (&v)[16], float& a0, float& a1)
+__device__ __forceinline__ void consume_item_sse(const float* qp, uint32_t nld, const float4 (&v)[8], float& a)
 {
 #pragma unroll
-    for (int k = 0; k < 16; k++)
-        if (FULL || (uint32_t)k < nch) {
-            const float2 q = *reinterpret_cast<const float2*>(qp + 4 * k);
-            const float t0 = v[k].x - q.x, t1 = v[k].y - q.y;
-            a0 = __builtin_fmaf(t0, t0, a0);
-            a1 = __builtin_fmaf(t1, t1, a1);
+    for (int t = 0; t < 8; t++)
+        if (FULL || (uint32_t)t < nld) {
+            const float4 q = *reinterpret_cast<const float4*>(qp + 32 * (t >> 1) + 4 * (t & 1));
+            const float t0 = v[t].x - q.x, t1 = v[t].y - q.y, t2 = v[t].z - q.z, t3 = v[t].w - q.w;
+            a = __builtin_fmaf(t0, t0, a); a = __builtin_fmaf(t1, t1, a);
+            a = __builtin_fmaf(t2, t2, a); a = __builtin_fmaf(t3, t3, a);
         }
 }
 
-// Scalar order: whole chunks, one running sum; squares are rounded before the add for the
-// first 4*(d/4) dims and fused for the last d%4 (what g++ 11 emits for that loop).
-template <bool FULL>
-__device__ __forceinline__ void issue_group(const float* rp, uint32_t nch, float4 (&v)[8])
-{
-#pragma unroll
-    for (int k = 0; k < 8; k++)
-        if (FULL || (uint32_t)k < nch) v[k] = *reinterpret_cast<const float4*>(rp + 4 * k);
-}
+__device__ __forceinline__ float f4_get(const float4& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
 
+// Scalar order: one line (8 loads, laid out [j][k]) consumed in dim order 4k+j; squares are rounded
+// before the add for dims below d4 and fused for the last d%4 (what g++ 11 emits for that loop).
 template <bool FULL>
-__device__ __forceinline__ void consume_group(const float* qp, uint32_t nch, uint32_t e0, uint32_t d4, const float4 (&v)[8], float& a)
+__device__ __forceinline__ void consume_item_scalar(const float* qp, uint32_t e0, uint32_t d4, const float4 (&v)[8], float& a)
 {
 #pragma unroll
-    for (int k = 0; k < 8; k++)
-        if (FULL || (uint32_t)k < nch) {
-            const float4 q = *reinterpret_cast<const float4*>(qp + 4 * k);
-            const float t0 = v[k].x - q.x, t1 = v[k].y - q.y, t2 = v[k].z - q.z, t3 = v[k].w - q.w;
+    for (int h = 0; h < 2; h++) {
+        float4 q[4];                       // the query's elements k = 4h..4h+3 of each sum j
+#pragma unroll
+        for (int j = 0; j < 4; j++) q[j] = *reinterpret_cast<const float4*>(qp + 8 * j + 4 * h);
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+            const int k = 4 * h + kk;
+            float tj[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) tj[j] = f4_get(v[2 * j + h], kk) - f4_get(q[j], kk);
             if (FULL || e0 + 4 * k < d4) {
-                const float s0 = t0 * t0, s1 = t1 * t1, s2 = t2 * t2, s3 = t3 * t3;
-                a = a + s0; a = a + s1; a = a + s2; a = a + s3;
+#pragma unroll
+                for (int j = 0; j < 4; j++) { const float sq = tj[j] * tj[j]; a = a + sq; }
             } else {
-                a = __builtin_fmaf(t0, t0, a); a = __builtin_fmaf(t1, t1, a);
-                a = __builtin_fmaf(t2, t2, a); a = __builtin_fmaf(t3, t3, a);
-            }
-        }
-}
-
-// Distance from the query to the row `row` points at, for the lanes with `active` set; the
-// result is valid in the first lane of every row's lane group.  Called by all 64 lanes.
-template <bool SCALAR>
-__device__ __forceinline__ float row_distance(const DistCtx& c, const float* row, bool active, int lane)
-{
-    typedef RowMap<SCALAR> RM;
-    float a0 = 0.0f, a1 = 0.0f;
-    DIAG_STAMP(d0);
-    if (active) {
-        const uint32_t ng = c.ngroups, nf = c.nfull, tc = c.tail_chunks;
-        if (SCALAR) {
-            float4 A[8], B[8];
-            const float* qs = c.qs;
-            if (0 < nf) issue_group<true>(row, 0, A); else issue_group<false>(row, tc, A);
-            if (ng > 1) { if (1 < nf) issue_group<true>(row + RM::kGroupFloats, 0, B); else issue_group<false>(row + RM::kGroupFloats, tc, B); }
-            for (uint32_t g = 0; g < ng; g += 2) {
-                if (g < nf) consume_group<true>(qs + g * RM::kGroupFloats, 0, 0, 0, A, a0);
-                else consume_group<false>(qs + g * RM::kGroupFloats, tc, g * RM::kGroupFloats, c.d4, A, a0);
-                if (g + 2 < ng) {
-                    if (g + 2 < nf) issue_group<true>(row + (g + 2) * RM::kGroupFloats, 0, A);
-                    else issue_group<false>(row + (g + 2) * RM::kGroupFloats, tc, A);
-                }
-                if (g + 1 < ng) {
-                    if (g + 1 < nf) consume_group<true>(qs + (g + 1) * RM::kGroupFloats, 0, 0, 0, B, a0);
-                    else consume_group<false>(qs + (g + 1) * RM::kGroupFloats, tc, (g + 1) * RM::kGroupFloats, c.d4, B, a0);
-                    if (g + 3 < ng) {
-                        if (g + 3 < nf) issue_group<true>(row + (g + 3) * RM::kGroupFloats, 0, B);
-                        else issue_group<false>(row + (g + 3) * RM::kGroupFloats, tc, B);
-                    }
-                }
-            }
-        } else {
-            float2 A[16], B[16];
-            const int p = lane & 1;
-            const float* rp = row + 2 * p;
-            const float* qs = c.qs + 2 * p;
-            if (0 < nf) issue_group<true>(rp, 0, A); else issue_group<false>(rp, tc, A);
-            if (ng > 1) { if (1 < nf) issue_group<true>(rp + RM::kGroupFloats, 0, B); else issue_group<false>(rp + RM::kGroupFloats, tc, B); }
-            for (uint32_t g = 0; g < ng; g += 2) {
-                if (g < nf) consume_group<true>(qs + g * RM::kGroupFloats, 0, A, a0, a1);
-                else consume_group<false>(qs + g * RM::kGroupFloats, tc, A, a0, a1);
-                if (g + 2 < ng) {
-                    if (g + 2 < nf) issue_group<true>(rp + (g + 2) * RM::kGroupFloats, 0, A);
-                    else issue_group<false>(rp + (g + 2) * RM::kGroupFloats, tc, A);
-                }
-                if (g + 1 < ng) {
-                    if (g + 1 < nf) consume_group<true>(qs + (g + 1) * RM::kGroupFloats, 0, B, a0, a1);
-                    else consume_group<false>(qs + (g + 1) * RM::kGroupFloats, tc, B, a0, a1);
-                    if (g + 3 < ng) {
-                        if (g + 3 < nf) issue_group<true>(rp + (g + 3) * RM::kGroupFloats, 0, B);
-                        else issue_group<false>(rp + (g + 3) * RM::kGroupFloats, tc, B);
-                    }
-                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) a = __builtin_fmaf(tj[j], tj[j], a);
             }
         }
     }
-    DIAG_STAMP(d1);
-    DIAG_ADD(c.cy_chain, d0, d1);
-    if (SCALAR) return a0;
-    // sums 0,1 are in the even lane of the pair, sums 2,3 in the odd one: ((s0 + s1) + s2) + s3
-    const float s2 = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(a0), 0xF5, 0xF, 0xF, false));   // quad_perm [1,1,3,3]
-    const float s3 = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(a1), 0xF5, 0xF, 0xF, false));
-    return ((a0 + a1) + s2) + s3;
 }
+
+// Distances from the query to up to kSub rows per lane group: row[s] points at the stored row
+// (already offset to this lane's part), act[s] says whether the lane takes part.  out[s] is
+// valid in every lane of the row's group.  Called by all 64 lanes.  The loads of two items are
+// in flight at any time; with rows of up to 128 dims that is both sub-batches of an SSE batch.
+template <bool SCALAR>
+__device__ __forceinline__ void batch_distance(const DistCtx& c, const float* const (&row)[RowMap<SCALAR>::kSub],
+                                               const bool (&act)[RowMap<SCALAR>::kSub], float (&out)[RowMap<SCALAR>::kSub], int lane)
+{
+    typedef RowMap<SCALAR> RM;
+    const uint32_t ni = c.nitems, nf = c.nfull, tl = c.tail_loads;
+    const float* qs = c.qs + (SCALAR ? 0 : 8 * (lane & 3));
+    float acc[RM::kSub];
+#pragma unroll
+    for (int s = 0; s < RM::kSub; s++) acc[s] = 0.0f;
+    float4 A[8], B[8];
+    // item i of the sequence: sub-batch i / ni, item i % ni of its rows
+    const uint32_t total = RM::kSub * ni;
+    auto issue = [&](float4 (&v)[8], uint32_t i) {
+        const uint32_t s = SCALAR ? 0u : (i >= ni ? 1u : 0u), g = i - s * ni;
+        const float* p = (s ? row[RM::kSub - 1] : row[0]) + g * RM::kItemFloats;
+        if (s ? act[RM::kSub - 1] : act[0]) { if (g < nf) issue_item<SCALAR, true>(p, 0, v); else issue_item<SCALAR, false>(p, tl, v); }
+    };
+    auto consume = [&](const float4 (&v)[8], uint32_t i) {
+        const uint32_t s = SCALAR ? 0u : (i >= ni ? 1u : 0u), g = i - s * ni;
+        const float* qp = qs + g * RM::kItemFloats;
+        float a = s ? acc[RM::kSub - 1] : acc[0];
+        if (s ? act[RM::kSub - 1] : act[0]) {
+            if (SCALAR) { if (g < nf) consume_item_scalar<true>(qp, 0, 0, v, a); else consume_item_scalar<false>(qp, g * RM::kItemFloats, c.d4, v, a); }
+            else { if (g < nf) consume_item_sse<true>(qp, 0, v, a); else consume_item_sse<false>(qp, tl, v, a); }
+        }
+        if (s) acc[RM::kSub - 1] = a; else acc[0] = a;
+    };
+    issue(A, 0);
+    if (total > 1) issue(B, 1);
+    for (uint32_t i = 0; i < total; i += 2) {
+        consume(A, i);
+        if (i + 2 < total) issue(A, i + 2);
+        if (i + 1 < total) {
+            consume(B, i + 1);
+            if (i + 3 < total) issue(B, i + 3);
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < RM::kSub; s++) {
+        if (SCALAR) { out[s] = acc[s]; continue; }
+        // sums 0..3 of a row sit in the 4 lanes of its quad: ((s0 + s1) + s2) + s3
+        const int ai = (int)__float_as_uint(acc[s]);
+        const float a0 = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, ai, 0x00, 0xF, 0xF, false));
+        const float a1 = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, ai, 0x55, 0xF, 0xF, false));
+        const float a2 = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, ai, 0xAA, 0xF, 0xF, false));
+        const float a3 = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, ai, 0xFF, 0xF, 0xF, false));
+        out[s] = ((a0 + a1) + a2) + a3;
+    }
+}
+
+// A lane's view of one batch of a neighbour list.  In SSE mode lane (r, j) of quad r serves row r of
+// sub-batch 0 and row 16 + r of sub-batch 1; the id, freshness and distance of sub-batch s are
+// kept "merged" in lane j == s of the quad, so one register and one ballot describe both.
+template <bool SCALAR>
+struct BatchLanes {
+    typedef RowMap<SCALAR> RM;
+    // row of the list this lane holds in merged form, or >= deg when none
+    static __device__ __forceinline__ uint32_t merged_row(int lane)
+    {
+        if (SCALAR) return (uint32_t)lane;
+        const uint32_t j = lane & 3, r = (uint32_t)lane >> 2;
+        return j < 2 ? j * 16u + r : 0xFFFFu;
+    }
+    // value of sub-batch s for every lane of the quad, from the merged register
+    static __device__ __forceinline__ uint32_t spread(uint32_t merged, int s)
+    {
+        if (SCALAR) return merged;
+        if (s == 0) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)merged, 0x00, 0xF, 0xF, false);   // quad_perm [0,0,0,0]
+        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)merged, 0x55, 0xF, 0xF, false);               // quad_perm [1,1,1,1]
+    }
+    // the lanes of `mask` in list order: sub-batch 0 (lanes 4r) before sub-batch 1 (lanes 4r+1)
+    static __device__ __forceinline__ int first_in_list_order(unsigned long long mask)
+    {
+        if (SCALAR) return __builtin_ctzll(mask);
+        const unsigned long long m0 = mask & 0x1111111111111111ull;
+        return __builtin_ctzll(m0 ? m0 : mask);
+    }
+};
 
 // WR = 0: the result list W is the libstdc++ max-heap in LDS, maintained exactly as the
 //         reference does (so even the choice among several equally distant worst entries
@@ -451,10 +479,11 @@ template <bool SCALAR, int WR>
 __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
 {
     typedef RowMap<SCALAR> RM;
+    typedef BatchLanes<SCALAR> BL;
     extern __shared__ __align__(16) uint32_t smem[];
     const int lane = threadIdx.x;
-    const uint32_t r = (uint32_t)lane / RM::kLanesPerRow;              // row of the batch this lane works on
-    const bool owner = (lane % RM::kLanesPerRow) == 0;                // the lane that holds the row's id and distance
+    const uint32_t mrow = BL::merged_row(lane);
+    const uint32_t lane_off = SCALAR ? 0u : 8u * (lane & 3);          // this lane's part of every stored line
     uint32_t qi = blockIdx.x;
     if (a.qmap) qi = a.qmap[qi];
 
@@ -472,10 +501,10 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
     const bool float_keys = (a.flags & HNSW_AMD_KEYS_FLOAT) != 0;
     const uint32_t ef = a.ef;
 
-    // query into LDS (zero padded), visited set empty
+    // query into LDS in stored form (zero padded), visited set empty
     {
         const float* q = a.queries + (size_t)qi * a.g.d;
-        for (uint32_t i = lane; i < a.qpad; i += 64) qs[i] = i < a.g.d ? q[i] : 0.0f;
+        for (uint32_t i = lane; i < a.qpad; i += 64) qs[stored_pos(i)] = i < a.g.d ? q[i] : 0.0f;
         for (uint32_t i = lane; i < H; i += 64) hash[i] = kEmpty;
     }
     LDS_SYNC();
@@ -493,8 +522,11 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
     float cur_dist;
     if (lane == 0) visited_insert(hash, hmask, hshift, cur_id);
     {
-        const float dj = row_distance<SCALAR>(dc, vectors + (size_t)cur_id * row_stride, r == 0, lane);
-        cur_dist = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(dj), 0));
+        const float* row[RM::kSub]; bool act[RM::kSub]; float dj[RM::kSub];
+#pragma unroll
+        for (int s = 0; s < RM::kSub; s++) { row[s] = vectors + (size_t)cur_id * row_stride + lane_off; act[s] = s == 0 && lane < RM::kLanesPerRow; }
+        batch_distance<SCALAR>(dc, row, act, dj, lane);
+        cur_dist = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(dj[0]), 0));
     }
     st.n_dist = 1;
     uint32_t nvis = 1;
@@ -513,24 +545,29 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
             // only on a strict improvement, i.e. to the first minimum of the list.
             const size_t rowi = (size_t)(base + cur_slot) * a.g.degu;
             for (uint32_t b0 = 0; b0 < a.g.degu; b0 += RM::kRowsPerBatch) {
-                uint32_t my_order = kEmpty, my_slot = kEmpty;
-                if (b0 + r < a.g.degu) { my_order = a.g.up_adj_order[rowi + b0 + r]; my_slot = a.g.up_adj_slot[rowi + b0 + r]; }
+                uint32_t my_order = kEmpty, my_slot = kEmpty;           // merged form
+                if (b0 + mrow < a.g.degu) { my_order = a.g.up_adj_order[rowi + b0 + mrow]; my_slot = a.g.up_adj_slot[rowi + b0 + mrow]; }
                 const bool live = my_order != kEmpty;
-                bool fresh = live && owner && visited_insert(hash, hmask, hshift, my_order);
-                if (RM::kLanesPerRow == 2) fresh = __builtin_amdgcn_update_dpp(0, (int)fresh, 0xA0, 0xF, 0xF, false) != 0;   // quad_perm [0,0,2,2]
-                const uint32_t m = (uint32_t)__popcll(__ballot(fresh && owner));
-                st.sum_degu += (uint32_t)__popcll(__ballot(live && owner));
+                const bool fresh = live && visited_insert(hash, hmask, hshift, my_order);
+                const uint32_t m = (uint32_t)__popcll(__ballot(fresh));
+                st.sum_degu += (uint32_t)__popcll(__ballot(live));
                 st.n_dist += m; nvis += m;
                 LDS_SYNC();
                 if (m == 0) continue;
-                const float dj = row_distance<SCALAR>(dc, vectors + (size_t)my_order * row_stride, fresh, lane);
-                const bool mine = fresh && owner && dj == dj;
-                const uint32_t key = mine ? __float_as_uint(dj) : 0x7F800000u;     // non-negative floats order as their bit patterns
+                const float* row[RM::kSub]; bool act[RM::kSub]; float dj[RM::kSub];
+#pragma unroll
+                for (int s = 0; s < RM::kSub; s++) {
+                    row[s] = vectors + (size_t)BL::spread(my_order, s) * row_stride + lane_off;
+                    act[s] = BL::spread((uint32_t)fresh, s) != 0;
+                }
+                batch_distance<SCALAR>(dc, row, act, dj, lane);
+                const float dm = (!SCALAR && (lane & 3) == 1) ? dj[RM::kSub - 1] : dj[0];      // merged form
+                const bool mine = fresh && dm == dm;
+                const uint32_t key = mine ? __float_as_uint(dm) : 0x7F800000u;     // non-negative floats order as their bit patterns
                 const uint32_t kmin = wave_min_u32(key);
                 const float bd = __uint_as_float(kmin);
                 if (bd < cur_dist) {
-                    const unsigned long long who = __ballot(mine && key == kmin);
-                    const int j = __builtin_ctzll(who);
+                    const int j = BL::first_in_list_order(__ballot(mine && key == kmin));
                     change = true;
                     cur_dist = bd;
                     cur_id = __builtin_amdgcn_readlane(my_order, j);
@@ -565,12 +602,12 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
         while (nC > 0 && !fail) {
             DIAG_STAMP(t0);
             uint32_t ckey, cid;
-            uint32_t my = kEmpty;
+            uint32_t my = kEmpty;                                   // merged form
             {
                 const uint2 c = C[0];
                 ckey = rfl(c.x); cid = rfl(c.y);
                 // the candidate's neighbour list is requested now and arrives while the heap is repaired
-                if (r < a.g.deg0) my = a.g.adj0[(size_t)cid * a.g.deg0 + r];
+                if (mrow < a.g.deg0) my = a.g.adj0[(size_t)cid * a.g.deg0 + mrow];
                 if (nC > 1) {
                     if (nC <= kWaveHeapMax) heap_pop_wave<COrder>(C, nC, lane);
                     else if (lane == 0) c_pop(C, nC);
@@ -587,27 +624,38 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
                 DIAG_STAMP(t1b);
                 if (nvis + 64 > visit_limit) { fail = 1; break; }
                 const bool live = my != kEmpty;
-                const uint32_t nlive = (uint32_t)__popcll(__ballot(live && owner));
-                bool fresh = live && owner && visited_insert(hash, hmask, hshift, my);
-                if (RM::kLanesPerRow == 2) fresh = __builtin_amdgcn_update_dpp(0, (int)fresh, 0xA0, 0xF, 0xF, false) != 0;   // quad_perm [0,0,2,2]
-                const uint32_t m = (uint32_t)__popcll(__ballot(fresh && owner));
+                const uint32_t nlive = (uint32_t)__popcll(__ballot(live));
+                const bool fresh = live && visited_insert(hash, hmask, hshift, my);
+                const uint32_t m = (uint32_t)__popcll(__ballot(fresh));
                 st.sum_deg0 += nlive; st.n_dist += m; nvis += m;
                 LDS_SYNC();
                 DIAG_STAMP(t2);
                 DIAG_ADD(cy_adj, t1b, t2);
                 if (m != 0) {
-                    const float dj = row_distance<SCALAR>(dc, vectors + (size_t)my * row_stride, fresh, lane);
+                    const float* row[RM::kSub]; bool act[RM::kSub]; float dj[RM::kSub];
+#pragma unroll
+                    for (int s = 0; s < RM::kSub; s++) {
+                        row[s] = vectors + (size_t)BL::spread(my, s) * row_stride + lane_off;
+                        act[s] = BL::spread((uint32_t)fresh, s) != 0;
+                    }
+                    batch_distance<SCALAR>(dc, row, act, dj, lane);
+                    const float dm = (!SCALAR && (lane & 3) == 1) ? dj[RM::kSub - 1] : dj[0];      // merged form
                     DIAG_STAMP(t3);
                     DIAG_ADD(cy_dist, t2, t3);
                     // Admission in list order (src/hnsw.cpp:765-777).  A neighbour that fails
                     // `dist < f` against the f at the start of the expansion can only be admitted
                     // while W is not full; f never grows once W is full, so skipping the others is exact.
-                    unsigned long long todo = __ballot(fresh && owner && (dj < f || nW < ef));
-                    if (nC + (uint32_t)__popcll(todo) > a.cap_c) { fail = 2; break; }
+                    const unsigned long long cand = __ballot(fresh && (dm < f || nW < ef));
+                    if (nC + (uint32_t)__popcll(cand) > a.cap_c) { fail = 2; break; }
+                    // list order: sub-batch 0 (lanes 4r) first, then sub-batch 1 (lanes 4r+1)
+                    unsigned long long todo = SCALAR ? cand : (cand & 0x1111111111111111ull);
+                    unsigned long long later = SCALAR ? 0ull : (cand & 0x2222222222222222ull);
+                    if (!todo) { todo = later; later = 0; }
                     while (todo) {
                         const int j = __builtin_ctzll(todo);
                         todo &= todo - 1;
-                        const float dist = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(dj), j));
+                        if (!todo) { todo = later; later = 0; }
+                        const float dist = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(dm), j));
                         if (dist < f || nW < ef) {
                             const uint32_t id = __builtin_amdgcn_readlane(my, j);
                             const uint2 ce = make_uint2(float_keys ? __float_as_uint(dist) : (uint32_t)trunc_key(dist), id);
@@ -673,7 +721,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
                 // the live entries of a list are a prefix: a batch with a gap was the last one
                 b0 += RM::kRowsPerBatch;
                 if (b0 >= a.g.deg0 || nlive < (uint32_t)RM::kRowsPerBatch) break;
-                my = b0 + r < a.g.deg0 ? a.g.adj0[(size_t)cid * a.g.deg0 + b0 + r] : kEmpty;
+                my = b0 + mrow < a.g.deg0 ? a.g.adj0[(size_t)cid * a.g.deg0 + b0 + mrow] : kEmpty;
             }
         }
     }
@@ -718,14 +766,23 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
         DIAG_STAMP(t_end);
         DIAG_ADD(cy_fin, t_l0_end, t_end);
         st.max_c = st.n_expand;
-        st.n_dist = dc.cy_chain; st.n_expand = cy_adj; st.n_sweeps = cy_dist; st.sum_deg0 = cy_adm;
+        st.n_dist = cy_up; st.n_expand = cy_adj; st.n_sweeps = cy_dist; st.sum_deg0 = cy_adm;
         st.sum_degu = cy_pop; st.n_visited0 = cy_fin; st.n_visited_up = (uint32_t)(t_end - t_begin);
-        (void)cy_up;
     }
 #endif
     if (lane == 0) {
         if (a.out_count) a.out_count[qi] = nW;
         if (a.stats) a.stats[qi] = st;
+    }
+}
+
+// Rows as the caller has them (n x d, dense) -> stored form (n x row_stride, regrouped lines, zero padded).
+__global__ void store_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, uint32_t rows, uint32_t d, uint32_t row_stride)
+{
+    const size_t total = (size_t)rows * row_stride;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t row = (uint32_t)(i / row_stride), dim = (uint32_t)(i % row_stride);
+        dst[(size_t)row * row_stride + stored_pos(dim)] = dim < d ? src[(size_t)row * d + dim] : 0.0f;
     }
 }
 
@@ -774,19 +831,27 @@ void DeviceIndex::upload(const HostIndex& h, int dev)
     g.n = fg.n; g.d = fg.d; g.nlayers = fg.nlayers; g.deg0 = fg.deg0; g.degu = fg.degu;
     g.row_stride = (fg.d + 31u) & ~31u;
     g.top_ep_slot = fg.ep_slot[fg.nlayers - 1]; g.top_ep_order = fg.ep_order[fg.nlayers - 1];
-    // base vectors: row-major, every row padded with zeros to whole 128-byte lines
+    // base vectors: row-major, every row padded with zeros to whole 128-byte lines, the dims of a
+    // line regrouped by lane sum (stored_pos); converted on the device, a slab of rows at a time
     {
         float* dv = nullptr;
         const size_t bytes = (size_t)g.n * g.row_stride * sizeof(float);
         HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&dv), bytes));
         bufs_[0] = dv;
-        if (g.row_stride == g.d) {
-            HIP_CHECK(hipMemcpy(dv, h.vector_data_.data(), bytes, hipMemcpyHostToDevice));
-        } else {
-            HIP_CHECK(hipMemset(dv, 0, bytes));
-            HIP_CHECK(hipMemcpy2D(dv, (size_t)g.row_stride * 4, h.vector_data_.data(), (size_t)g.d * 4, (size_t)g.d * 4, g.n,
-                                  hipMemcpyHostToDevice));
+        const uint32_t slab = (uint32_t)std::max<size_t>(1, std::min<size_t>(g.n, ((size_t)64 << 20) / g.d));
+        float* tmp = nullptr;
+        HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&tmp), (size_t)slab * g.d * sizeof(float)));
+        for (uint32_t r0 = 0; r0 < g.n; r0 += slab) {
+            const uint32_t rows = std::min(slab, g.n - r0);
+            hipError_t e = hipMemcpy(tmp, h.vector_data_.data() + (size_t)r0 * g.d, (size_t)rows * g.d * sizeof(float), hipMemcpyHostToDevice);
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(store_rows_kernel, dim3(4096), dim3(256), 0, 0, tmp, dv + (size_t)r0 * g.row_stride, rows, g.d, g.row_stride);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess) e = hipDeviceSynchronize();
+            if (e != hipSuccess) { (void)hipFree(tmp); HIP_CHECK(e); }
         }
+        HIP_CHECK(hipFree(tmp));
         g.vectors = dv;
     }
     g.adj0 = to_device(fg.adj0, bufs_[1]);

@@ -14,7 +14,9 @@ for pass in \
   "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT" \
   "FETCH_SIZE TCC_HIT_sum" \
   "WRITE_SIZE TCC_MISS_sum TCC_REQ_sum" \
-  "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" ; do
+  "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" \
+  "TA_TA_BUSY_sum TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_GATE_EN2_sum" \
+  "SQ_INST_CYCLES_VMEM SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAIT_INST_LDS SQ_ACTIVE_INST_FLAT SQ_INSTS_FLAT SQ_WAVES" ; do
   i=$((i+1))
   timeout -s KILL 120 rocprofv3 --pmc $pass --output-format csv -d $OUT/p$i -- python3 $R/tools/run_search.py --cache /tmp/g1m.npz --reps 2 "$@" > $OUT/p$i.log 2>&1
   echo "pass $i rc=$?"
