@@ -210,32 +210,32 @@ __device__ __forceinline__ uint2 heap_pop_wave(uint2* a, uint32_t n /* size befo
     const uint32_t len = n - 1;
     const uint2 v = a[len];
     const uint32_t nint = (len - 1) >> 1;      // nodes with both children inside [0, len)
-    // lane i (+64, +128, +192): the child node i hands the hole to
-    uint32_t nx0 = 0, nx1 = 0, nx2 = 0, nx3 = 0;
+    // bit i of the masks: node i hands the hole to its LEFT child (comp(right, left))
+    unsigned long long m0 = 0, m1 = 0, m2 = 0, m3 = 0;
     {
         uint32_t i = lane;
-        if (i < nint) nx0 = 2 * i + 2 - (Ord::before(a[2 * i + 2], a[2 * i + 1]) ? 1u : 0u);
-        if (nint > 64)  { i = lane + 64;  if (i < nint) nx1 = 2 * i + 2 - (Ord::before(a[2 * i + 2], a[2 * i + 1]) ? 1u : 0u); }
-        if (nint > 128) { i = lane + 128; if (i < nint) nx2 = 2 * i + 2 - (Ord::before(a[2 * i + 2], a[2 * i + 1]) ? 1u : 0u); }
-        if (nint > 192) { i = lane + 192; if (i < nint) nx3 = 2 * i + 2 - (Ord::before(a[2 * i + 2], a[2 * i + 1]) ? 1u : 0u); }
+        m0 = __ballot(i < nint && Ord::before(a[2 * i + 2], a[2 * i + 1]));
+        if (nint > 64)  { i = lane + 64;  m1 = __ballot(i < nint && Ord::before(a[2 * i + 2], a[2 * i + 1])); }
+        if (nint > 128) { i = lane + 128; m2 = __ballot(i < nint && Ord::before(a[2 * i + 2], a[2 * i + 1])); }
+        if (nint > 192) { i = lane + 192; m3 = __ballot(i < nint && Ord::before(a[2 * i + 2], a[2 * i + 1])); }
     }
-    // walk the hole down; lane k records step k of the path (from -> to)
-    uint32_t cur = 0, d = 0, my_from = 0, my_to = 0;
-    while (cur < nint) {
-        const uint32_t w = cur >> 6, l = cur & 63;
-        uint32_t nxt;
-        if (w == 0) nxt = __builtin_amdgcn_readlane(nx0, l);
-        else if (w == 1) nxt = __builtin_amdgcn_readlane(nx1, l);
-        else if (w == 2) nxt = __builtin_amdgcn_readlane(nx2, l);
-        else nxt = __builtin_amdgcn_readlane(nx3, l);
-        if ((uint32_t)lane == d) { my_from = nxt; my_to = cur; }
-        cur = nxt; d++;
+    // Walk the hole down on the scalar unit, in 1-based indices: the children of p are 2p (left) and
+    // 2p+1 (right), so the path is the bit string of the final index and step k of it is a shift.
+    uint32_t p = 1, d = 0;
+    {
+        const uint32_t lim0 = nint < 63u ? nint : 63u;       // nodes 0..62 (six levels) are all in m0
+        while (p - 1 < lim0) { p = 2 * p + 1 - (uint32_t)((m0 >> (p - 1)) & 1ull); d++; }
+        while (p - 1 < nint) {
+            const uint32_t idx = p - 1;
+            const unsigned long long m = idx < 64 ? m0 : (idx < 128 ? m1 : (idx < 192 ? m2 : m3));
+            p = 2 * p + 1 - (uint32_t)((m >> (idx & 63u)) & 1ull); d++;
+        }
     }
-    if ((len & 1u) == 0 && cur == (len - 2) >> 1) {      // a last node with a left child only
-        const uint32_t nxt = 2 * cur + 1;
-        if ((uint32_t)lane == d) { my_from = nxt; my_to = cur; }
-        cur = nxt; d++;
-    }
+    if ((len & 1u) == 0 && p - 1 == (len - 2) >> 1) { p = 2 * p; d++; }     // a last node with a left child only
+    const uint32_t cur = p - 1;                                              // where the hole ends up
+    // lane k owns step k of the path: the element at my_from moves up to my_to
+    const uint32_t sh = d - (uint32_t)lane;                                  // meaningful for lane < d
+    const uint32_t my_to = (p >> (sh & 31u)) - 1, my_from = (p >> ((sh - 1) & 31u)) - 1;
     uint2 x = make_uint2(0, 0);
     bool c = false;
     if ((uint32_t)lane < d) { x = a[my_from]; c = Ord::before(x, v); }
@@ -664,7 +664,19 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
                             if (WR > 0) {
                                 if (nC <= kWaveHeapMax) heap_push_wave<COrder>(C, nC, ce, lane);
                                 else { if (lane == 0) { C[nC - 1] = ce; c_push(C, nC); } }
-                                if (nW < ef) {
+                                if (WR == 1) {
+                                    // one entry per lane, kept ascending over lanes 0..nW-1: the new entry goes behind
+                                    // the entries not larger than it, the rest move up one lane, and with W full
+                                    // the largest one falls off the end
+                                    const unsigned long long valid = nW < 64 ? (1ull << nW) - 1ull : ~0ull;
+                                    const uint32_t pos = (uint32_t)__popcll(__ballot(wd[0] <= we.x) & valid);
+                                    const uint32_t sd = (uint32_t)__builtin_amdgcn_update_dpp((int)wd[0], (int)wd[0], 0x138, 0xF, 0xF, false);   // wave_shr:1
+                                    const uint32_t si = (uint32_t)__builtin_amdgcn_update_dpp((int)wi[0], (int)wi[0], 0x138, 0xF, 0xF, false);
+                                    if ((uint32_t)lane > pos) { wd[0] = sd; wi[0] = si; }
+                                    if ((uint32_t)lane == pos) { wd[0] = we.x; wi[0] = we.y; }
+                                    if (nW < ef) nW++;
+                                    f = __uint_as_float(__builtin_amdgcn_readlane(wd[0], nW - 1));
+                                } else if (nW < ef) {
                                     // W not full: append; f stays the largest distance in W
 #pragma unroll
                                     for (int w = 0; w < WR; w++)
