@@ -439,9 +439,10 @@ __device__ __forceinline__ void batch_distance(const DistCtx& c, const float* co
     }
 }
 
-// A lane's view of one batch of a neighbour list.  In SSE mode lane (r, j) of quad r serves row r of
-// sub-batch 0 and row 16 + r of sub-batch 1; the id, freshness and distance of sub-batch s are
-// kept "merged" in lane j == s of the quad, so one register and one ballot describe both.
+// A lane's view of one batch of a neighbour list.  In SSE mode lane (r, j) of quad r serves row 2r
+// (sub-batch 0) and row 2r + 1 (sub-batch 1); the id, freshness and distance of sub-batch s are
+// kept "merged" in lane j == s of the quad, so one register and one ballot describe both, and
+// lane order is list order.
 template <bool SCALAR>
 struct BatchLanes {
     typedef RowMap<SCALAR> RM;
@@ -450,7 +451,7 @@ struct BatchLanes {
     {
         if (SCALAR) return (uint32_t)lane;
         const uint32_t j = lane & 3, r = (uint32_t)lane >> 2;
-        return j < 2 ? j * 16u + r : 0xFFFFu;
+        return j < 2 ? 2u * r + j : 0xFFFFu;
     }
     // value of sub-batch s for every lane of the quad, from the merged register
     static __device__ __forceinline__ uint32_t spread(uint32_t merged, int s)
@@ -458,13 +459,6 @@ struct BatchLanes {
         if (SCALAR) return merged;
         if (s == 0) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)merged, 0x00, 0xF, 0xF, false);   // quad_perm [0,0,0,0]
         return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)merged, 0x55, 0xF, 0xF, false);               // quad_perm [1,1,1,1]
-    }
-    // the lanes of `mask` in list order: sub-batch 0 (lanes 4r) before sub-batch 1 (lanes 4r+1)
-    static __device__ __forceinline__ int first_in_list_order(unsigned long long mask)
-    {
-        if (SCALAR) return __builtin_ctzll(mask);
-        const unsigned long long m0 = mask & 0x1111111111111111ull;
-        return __builtin_ctzll(m0 ? m0 : mask);
     }
 };
 
@@ -500,6 +494,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
     const DistCtx dc = make_dist_ctx<SCALAR>(qs, a.g.d);
     const bool float_keys = (a.flags & HNSW_AMD_KEYS_FLOAT) != 0;
     const uint32_t ef = a.ef;
+    const unsigned long long w_valid = ef < 64 ? (1ull << ef) - 1ull : ~0ull;     // lanes of a full one-entry-per-lane W
 
     // query into LDS in stored form (zero padded), visited set empty
     {
@@ -567,7 +562,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
                 const uint32_t kmin = wave_min_u32(key);
                 const float bd = __uint_as_float(kmin);
                 if (bd < cur_dist) {
-                    const int j = BL::first_in_list_order(__ballot(mine && key == kmin));
+                    const int j = __builtin_ctzll(__ballot(mine && key == kmin));
                     change = true;
                     cur_dist = bd;
                     cur_id = __builtin_amdgcn_readlane(my_order, j);
@@ -645,20 +640,39 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
                     // Admission in list order (src/hnsw.cpp:765-777).  A neighbour that fails
                     // `dist < f` against the f at the start of the expansion can only be admitted
                     // while W is not full; f never grows once W is full, so skipping the others is exact.
-                    const unsigned long long cand = __ballot(fresh && (dm < f || nW < ef));
-                    if (nC + (uint32_t)__popcll(cand) > a.cap_c) { fail = 2; break; }
-                    // list order: sub-batch 0 (lanes 4r) first, then sub-batch 1 (lanes 4r+1)
-                    unsigned long long todo = SCALAR ? cand : (cand & 0x1111111111111111ull);
-                    unsigned long long later = SCALAR ? 0ull : (cand & 0x2222222222222222ull);
-                    if (!todo) { todo = later; later = 0; }
+                    unsigned long long todo = __ballot(fresh && (dm < f || nW < ef));
+                    if (nC + (uint32_t)__popcll(todo) > a.cap_c) { fail = 2; break; }
+                    const uint32_t keym = float_keys ? __float_as_uint(dm) : (uint32_t)trunc_key(dm);
+                    if (WR == 1 && nW == ef) {
+                        // W is full (the usual state): its size and the lane of its largest entry are fixed
+                        while (todo) {
+                            const int j = __builtin_ctzll(todo);
+                            todo &= todo - 1;
+                            const uint32_t db = __builtin_amdgcn_readlane(__float_as_uint(dm), j);
+                            if (__uint_as_float(db) < f) {
+                                const uint32_t id = __builtin_amdgcn_readlane(my, j);
+                                const uint2 ce = make_uint2(__builtin_amdgcn_readlane(keym, j), id);
+                                nC++;
+                                if (nC <= kWaveHeapMax) heap_push_wave<COrder>(C, nC, ce, lane);
+                                else { if (lane == 0) { C[nC - 1] = ce; c_push(C, nC); } }
+                                const uint32_t pos = (uint32_t)__popcll(__ballot(wd[0] <= db) & w_valid);
+                                const uint32_t sd = (uint32_t)__builtin_amdgcn_update_dpp((int)wd[0], (int)wd[0], 0x138, 0xF, 0xF, false);   // wave_shr:1
+                                const uint32_t si = (uint32_t)__builtin_amdgcn_update_dpp((int)wi[0], (int)wi[0], 0x138, 0xF, 0xF, false);
+                                if ((uint32_t)lane > pos) { wd[0] = sd; wi[0] = si; }
+                                if ((uint32_t)lane == pos) { wd[0] = db; wi[0] = id; }
+                                f = __uint_as_float(__builtin_amdgcn_readlane(wd[0], ef - 1));
+                                LDS_SYNC();
+                            }
+                        }
+                        if (nC > st.max_c) st.max_c = nC;     // C only grows inside the loop
+                    } else
                     while (todo) {
                         const int j = __builtin_ctzll(todo);
                         todo &= todo - 1;
-                        if (!todo) { todo = later; later = 0; }
                         const float dist = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(dm), j));
                         if (dist < f || nW < ef) {
                             const uint32_t id = __builtin_amdgcn_readlane(my, j);
-                            const uint2 ce = make_uint2(float_keys ? __float_as_uint(dist) : (uint32_t)trunc_key(dist), id);
+                            const uint2 ce = make_uint2(__builtin_amdgcn_readlane(keym, j), id);
                             const uint2 we = make_uint2(__float_as_uint(dist), id);
                             nC++;
                             if (WR > 0) {
