@@ -3,18 +3,18 @@
 // One 64-lane wavefront (= one workgroup) runs one query from entry point to sorted
 // result, entirely on chip except for the adjacency rows and base vectors it gathers
 // from HBM:
-//   - query vector, candidate heap C, result heap W, exact visited hash set: LDS;
-//   - a neighbour list is one coalesced read (lane j reads neighbour j); the unvisited
-//     neighbours are compacted with a ballot, and their base-vector rows are gathered
-//     16 lanes per row (256 contiguous bytes per row per instruction, 4 rows per
-//     instruction), all rows of an expansion in flight together;
+//   - query vector, candidate heap C and the exact visited hash set: LDS; neighbour ids,
+//     distances and the result list W: registers;
+//   - a neighbour list is one coalesced read; rows already visited are masked out of the row
+//     loads (no compaction), and all row loads of an expansion are in flight together;
 //   - distances reproduce the reference's float arithmetic bit for bit: the 4 lane sums of
-//     its SSE loop are 4 sequential fused-multiply-add chains per row, so the differences
-//     are transposed through a small LDS tile and 64 lanes each run one (row, lane-sum)
-//     chain (16 rows x 4 sums at a time);
-//   - heap updates follow libstdc++'s push_heap/pop_heap step by step (one lane), because
-//     with the reference's int32 candidate keys ties are the rule and their pop order
-//     decides which nodes are expanded.
+//     its SSE loop are 4 sequential fused-multiply-add chains per row, run by the 4 lanes of
+//     a quad, each reading its own 32 bytes of every 128-byte line (the lines are stored
+//     regrouped by lane sum, see stored_pos);
+//   - heap updates follow libstdc++'s push_heap/pop_heap exactly, executed by the whole
+//     wavefront in a constant number of LDS round trips, because with the reference's
+//     int32 candidate keys ties are the rule and their pop order decides which nodes are
+//     expanded.
 // Follows reference src/hnsw.cpp:373-449 (aproximateKnn), :676-717 (searchLayerOne),
 // :725-787 (searchLayer), src/hnsw.h:334-400 (distance), :55-125 (visited set).
 #include <hip/hip_runtime.h>
