@@ -60,3 +60,35 @@ def test_unit_norm_float_keys_do_less_work_but_differ():
     _, _, _, st_i = h.search_batch(q, 64, flags=capi.DIST_SSE | capi.KEYS_INT32, stats=True)
     _, _, _, st_f = h.search_batch(q, 64, flags=capi.DIST_SSE | capi.KEYS_FLOAT, stats=True)
     assert st_f["n_dist"].mean() < 0.8 * st_i["n_dist"].mean()
+
+
+@pytest.mark.parametrize("M,kind,flags", [
+    (4, "sift", capi.DIST_SSE),                       # lists shorter than one sub-batch of rows
+    (24, "sift", capi.DIST_SSE),                      # layer-0 lists of 48: a full batch of 32 rows and half a second one
+    (32, "sift", capi.DIST_SSE),                      # layer-0 lists of 64: two full batches
+    (32, "deep", capi.DIST_SSE | capi.W_STD_HEAP),
+    (32, "glove", capi.DIST_SCALAR),                  # one lane per row: 64 rows in one batch
+    (12, "glove", capi.DIST_SCALAR | capi.KEYS_FLOAT),
+])
+def test_other_list_lengths_match_oracle(M, kind, flags):
+    """The kernel handles a neighbour list in batches of 32 rows (64 in scalar mode); lists of other
+    lengths than the benchmark's 2*16 exercise the partial and the repeated batch."""
+    n, nq = 12000, 200
+    base = datagen.make(kind, n, seed=5)
+    q = datagen.make(kind, nq, seed=5, stream=1)
+    h = HNSW(M, M, 100)
+    h.init(base.shape[1], n)
+    h.insert_batch(base, threads=16)
+    fg = h.export_flat()
+    fg.validate()
+    assert fg.deg0 == 2 * M
+    idx = oracle.OracleIndex(fg, base)
+    dist_mode = oracle.DIST_SCALAR if flags & capi.DIST_SCALAR else oracle.DIST_SSE
+    key_mode = oracle.KEYS_FLOAT if flags & capi.KEYS_FLOAT else oracle.KEYS_INT32
+    for ef in (8, 40, 100):
+        ids, dist, cnt, st = h.search_batch(q, ef, flags=flags, stats=True)
+        oi, od, oc, ost = idx.search(q, ef, dist_mode=dist_mode, key_mode=key_mode, stats=True, threads=8)
+        assert np.array_equal(cnt, oc)
+        assert_same_results(ids, dist, oi, od, what=f"M={M} {kind} ef={ef}")
+        for field in st.dtype.names:
+            assert np.array_equal(st[field], ost[field]), f"M={M} {kind} ef={ef}: counter {field}"
