@@ -51,6 +51,9 @@ def main():
     ap.add_argument("--keys", default="int32", choices=["int32", "float"])
     ap.add_argument("--dist", default="sse", choices=["sse", "scalar"],
                     help="sse: the shipped reference's distance (first 16*floor(d/16) dims); scalar: its -DNO_MANUAL_VECTORIZATION build (all dims)")
+    ap.add_argument("--rows", default="f32", choices=["f32", "u8"],
+                    help="u8: search the one-byte-per-dimension copy of the base (integer-valued data only; results unchanged); "
+                         "the algorithmic bytes are then counted at 1 byte per dimension")
     ap.add_argument("--sweep", default="", help="comma-separated ef values: report recall and QPS for each instead of one operating point")
     args = ap.parse_args()
 
@@ -119,6 +122,8 @@ def main():
     cnt_t = torch.empty((nq,), dtype=torch.int32, device=dev)
     stats_t = torch.empty((nq, 8), dtype=torch.int32, device=dev)
     flags = (capi.DIST_SCALAR if args.dist == "scalar" else capi.DIST_SSE) | (capi.KEYS_FLOAT if args.keys == "float" else capi.KEYS_INT32)
+    flags |= capi.ROWS_U8 if args.rows == "u8" else 0
+    row_elem_bytes = 1 if args.rows == "u8" else 4
     h.flags = flags
     offsets = np.array([r * args.n // world for r in range(world)], dtype=np.uint32)
     out_ids = torch.empty((nq, k), dtype=torch.int32, device=dev)
@@ -175,7 +180,7 @@ def main():
             if world == 1:
                 st = stats_t.cpu().numpy().view(np.uint32).reshape(nq, 8).copy().view(capi.STATS_DTYPE).reshape(nq)
                 rec["dist_per_query"] = round(float(st["n_dist"].mean()), 1)
-                bpl = int(harness.algorithmic_bytes(st, d, d if args.dist == "scalar" else d & ~15, k).sum())
+                bpl = int(harness.algorithmic_bytes(st, d, d if args.dist == "scalar" else d & ~15, k, row_elem_bytes).sum())
             t0 = time.perf_counter()
             for _ in range(3):
                 step(ef, k)
@@ -216,7 +221,7 @@ def main():
     step(ef, k, want_stats=True)
     torch.cuda.synchronize()
     st = stats_t.cpu().numpy().view(np.uint32).reshape(nq, 8).copy().view(capi.STATS_DTYPE).reshape(nq)
-    bytes_per_launch = int(harness.algorithmic_bytes(st, d, d if args.dist == "scalar" else d & ~15, k).sum())
+    bytes_per_launch = int(harness.algorithmic_bytes(st, d, d if args.dist == "scalar" else d & ~15, k, row_elem_bytes).sum())
     ids_final = out_ids.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
     # top-(k+1) for the reference's own "Precision" figure
     prec_ref = None
@@ -275,7 +280,7 @@ def main():
     # another workload does not apply
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "pmc_search_kernel_latest.json")
-    if world == 1 and os.path.exists(tpath) and args.n == 1_000_000 and nq == 10_000 and args.kind == "sift" and ef == 50:
+    if world == 1 and os.path.exists(tpath) and args.n == 1_000_000 and nq == 10_000 and args.kind == "sift" and ef == 50 and args.rows == "f32":
         with open(tpath) as f:
             pm = json.load(f)
         traffic = pm.get("hbm_read_bytes_x2", 0) + pm.get("hbm_write_bytes", 0) or None
@@ -363,7 +368,7 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.kind}-{d} synthetic, n={args.n}, nq={nq}, M=16, efConstruction=200, ef={ef}, k={k}, "
-                                   f"keys={args.keys}" + (f", {world} shards + RCCL all-gather + device merge" if world > 1 else ""),
+                                   f"keys={args.keys}, rows={args.rows}" + (f", {world} shards + RCCL all-gather + device merge" if world > 1 else ""),
                        "ef": ef, "recall_at_10": round(recall, 4), "reference_precision_top11": prec_ref,
                        "ef_sweep": sweep, "build_s": round(build_s, 1), "build_threads": args.build_threads,
                        "ground_truth": dict(gt_info, method="exact brute force, f32-input MFMA kernel of this library")},

@@ -20,6 +20,7 @@ OK, E_ARG, E_FULL, E_IO, E_HIP, E_SCRATCH, E_GRAPH = 0, -1, -2, -3, -4, -5, -6
 DIST_SSE, DIST_SCALAR = 0, 1
 KEYS_INT32, KEYS_FLOAT = 0, 2
 W_STD_HEAP = 4
+ROWS_U8 = 8
 
 _u32p = C.POINTER(C.c_uint32)
 _f32p = C.POINTER(C.c_float)

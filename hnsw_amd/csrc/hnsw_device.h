@@ -15,7 +15,9 @@ struct DeviceGraph {
     uint32_t row_stride;        // floats per stored row: d rounded up to a multiple of 32 (128-byte lines), zero filled
     uint32_t nlayers, deg0, degu;
     uint32_t top_ep_slot, top_ep_order;
-    const float* vectors;       // n x row_stride
+    const float* vectors;       // n x row_stride floats, the dims of every 128-byte line regrouped by lane sum
+    const uint8_t* vectors_u8;  // n x row_stride_u8 bytes, one per dim, or nullptr when some value is not an integer in 0..255
+    uint32_t row_stride_u8;     // d rounded up to a multiple of 128
     const uint32_t* adj0;       // n x deg0, 0xFFFFFFFF padded (the live entries are a prefix)
     const uint32_t* up_off;     // nlayers+1
     const uint32_t* up_down;    // U

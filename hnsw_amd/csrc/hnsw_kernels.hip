@@ -285,6 +285,15 @@ __host__ __device__ __forceinline__ uint32_t stored_pos(uint32_t dim)
     return (dim & ~31u) | ((dim & 3u) << 3) | ((dim >> 2) & 7u);
 }
 
+// Byte form of a base vector whose values are all integers in 0..255 (then float(byte) is the stored
+// float, exactly): one byte per dim, rows padded to 128 bytes, every 128-dim block regrouped by
+// lane sum: dim 128*b + 4*k + j (k = 0..31) sits at byte 128*b + 32*j + k, so chain j reads 32
+// contiguous bytes per block.  The query copy in LDS uses the same order (as floats).
+__host__ __device__ __forceinline__ uint32_t stored_pos_u8(uint32_t dim)
+{
+    return (dim & ~127u) | ((dim & 3u) << 5) | ((dim >> 2) & 31u);
+}
+
 // How the 64 lanes share the rows of a neighbour list.
 //  SCALAR=false (the SSE loop): the 4 lane sums of a row are 4 independent sequential fused-multiply-add
 //    chains in index order.  Four lanes per row, lane j runs chain j: it reads its 32 bytes of
@@ -350,6 +359,31 @@ __device__ __forceinline__ void consume_item_sse(const float* qp, uint32_t nld, 
         if (FULL || (uint32_t)t < nld) {
             const float4 q = *reinterpret_cast<const float4*>(qp + 32 * (t >> 1) + 4 * (t & 1));
             const float t0 = v[t].x - q.x, t1 = v[t].y - q.y, t2 = v[t].z - q.z, t3 = v[t].w - q.w;
+            a = __builtin_fmaf(t0, t0, a); a = __builtin_fmaf(t1, t1, a);
+            a = __builtin_fmaf(t2, t2, a); a = __builtin_fmaf(t3, t3, a);
+        }
+}
+
+// Byte rows, SSE order: an item is one 128-dim block, 2 x 16 bytes per lane; a dword holds 4
+// consecutive elements of the lane's chain (16 dims of the row).
+__device__ __forceinline__ void issue_item_u8(const uint8_t* p, uint4 (&v)[2])
+{
+    v[0] = *reinterpret_cast<const uint4*>(p);
+    v[1] = *reinterpret_cast<const uint4*>(p + 16);
+}
+
+__device__ __forceinline__ uint32_t u4_get(const uint4& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
+
+template <bool FULL>
+__device__ __forceinline__ void consume_item_u8(const float* qp, uint32_t nwords, const uint4 (&v)[2], float& a)
+{
+#pragma unroll
+    for (int w = 0; w < 8; w++)
+        if (FULL || (uint32_t)w < nwords) {
+            const float4 q = *reinterpret_cast<const float4*>(qp + 4 * w);
+            const uint32_t word = u4_get(v[w >> 2], w & 3);
+            const float t0 = (float)(word & 0xFFu) - q.x, t1 = (float)((word >> 8) & 0xFFu) - q.y;
+            const float t2 = (float)((word >> 16) & 0xFFu) - q.z, t3 = (float)(word >> 24) - q.w;
             a = __builtin_fmaf(t0, t0, a); a = __builtin_fmaf(t1, t1, a);
             a = __builtin_fmaf(t2, t2, a); a = __builtin_fmaf(t3, t3, a);
         }
@@ -439,6 +473,64 @@ __device__ __forceinline__ void batch_distance(const DistCtx& c, const float* co
     }
 }
 
+// The same for byte rows (SSE order only): row[s] points at this lane's 32 bytes of the row's first block.
+__device__ __forceinline__ void batch_distance_u8(const DistCtx& c, const uint8_t* const (&row)[2], const bool (&act)[2],
+                                                  float (&out)[2], int lane)
+{
+    const uint32_t ni = c.nitems, nf = c.nfull, tl = c.tail_loads;
+    const float* qs = c.qs + 32 * (lane & 3);
+    float acc[2] = {0.0f, 0.0f};
+    uint4 A[2], B[2];
+    const uint32_t total = 2 * ni;
+    auto issue = [&](uint4 (&v)[2], uint32_t i) {
+        const uint32_t s = i >= ni ? 1u : 0u, g = i - s * ni;
+        if (s ? act[1] : act[0]) issue_item_u8((s ? row[1] : row[0]) + g * 128u, v);
+    };
+    auto consume = [&](const uint4 (&v)[2], uint32_t i) {
+        const uint32_t s = i >= ni ? 1u : 0u, g = i - s * ni;
+        float a = s ? acc[1] : acc[0];
+        if (s ? act[1] : act[0]) { if (g < nf) consume_item_u8<true>(qs + g * 128u, 0, v, a); else consume_item_u8<false>(qs + g * 128u, tl, v, a); }
+        if (s) acc[1] = a; else acc[0] = a;
+    };
+    issue(A, 0);
+    issue(B, 1);
+    for (uint32_t i = 0; i < total; i += 2) {
+        consume(A, i);
+        if (i + 2 < total) issue(A, i + 2);
+        consume(B, i + 1);
+        if (i + 3 < total) issue(B, i + 3);
+    }
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        const int ai = (int)__float_as_uint(acc[s]);
+        const float a0 = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, ai, 0x00, 0xF, 0xF, false));
+        const float a1 = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, ai, 0x55, 0xF, 0xF, false));
+        const float a2 = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, ai, 0xAA, 0xF, 0xF, false));
+        const float a3 = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, ai, 0xFF, 0xF, 0xF, false));
+        out[s] = ((a0 + a1) + a2) + a3;
+    }
+}
+
+// Distances to the rows `id[s]` (sub-batch s; act[s]: the lane's row takes part), from the float or the byte table.
+template <bool SCALAR, bool U8>
+__device__ __forceinline__ void rows_distance(const DeviceGraph& g, const DistCtx& c, const uint32_t (&id)[RowMap<SCALAR>::kSub],
+                                              const bool (&act)[RowMap<SCALAR>::kSub], float (&out)[RowMap<SCALAR>::kSub], int lane)
+{
+    typedef RowMap<SCALAR> RM;
+    if constexpr (U8) {
+        static_assert(!SCALAR, "byte rows are read in SSE order only");
+        const uint8_t* row[2];
+#pragma unroll
+        for (int s = 0; s < 2; s++) row[s] = g.vectors_u8 + (size_t)id[s] * g.row_stride_u8 + 32u * (lane & 3);
+        batch_distance_u8(c, row, act, out, lane);
+    } else {
+        const float* row[RM::kSub];
+#pragma unroll
+        for (int s = 0; s < RM::kSub; s++) row[s] = g.vectors + (size_t)id[s] * g.row_stride + (SCALAR ? 0u : 8u * (lane & 3));
+        batch_distance<SCALAR>(c, row, act, out, lane);
+    }
+}
+
 // A lane's view of one batch of a neighbour list.  In SSE mode lane (r, j) of quad r serves row 2r
 // (sub-batch 0) and row 2r + 1 (sub-batch 1); the id, freshness and distance of sub-batch s are
 // kept "merged" in lane j == s of the quad, so one register and one ballot describe both, and
@@ -469,7 +561,8 @@ struct BatchLanes {
 //         largest distance f and the size of W steer the search, and both evolve
 //         identically; the one observable difference is which of several entries with
 //         exactly the worst distance is dropped.
-template <bool SCALAR, int WR>
+// U8: rows are read from the byte table (DeviceGraph::vectors_u8) instead of the float table.
+template <bool SCALAR, int WR, bool U8>
 __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
 {
     typedef RowMap<SCALAR> RM;
@@ -477,7 +570,6 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
     extern __shared__ __align__(16) uint32_t smem[];
     const int lane = threadIdx.x;
     const uint32_t mrow = BL::merged_row(lane);
-    const uint32_t lane_off = SCALAR ? 0u : 8u * (lane & 3);          // this lane's part of every stored line
     uint32_t qi = blockIdx.x;
     if (a.qmap) qi = a.qmap[qi];
 
@@ -489,8 +581,6 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
     uint32_t* hash = reinterpret_cast<uint32_t*>(C + a.cap_c);
     const uint32_t H = 1u << a.hash_bits, hmask = H - 1, hshift = 32 - a.hash_bits;
     const uint32_t visit_limit = H - (H >> 3);       // keep the table at most 7/8 full
-    const float* const vectors = a.g.vectors;
-    const uint32_t row_stride = a.g.row_stride;
     const DistCtx dc = make_dist_ctx<SCALAR>(qs, a.g.d);
     const bool float_keys = (a.flags & HNSW_AMD_KEYS_FLOAT) != 0;
     const uint32_t ef = a.ef;
@@ -499,7 +589,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
     // query into LDS in stored form (zero padded), visited set empty
     {
         const float* q = a.queries + (size_t)qi * a.g.d;
-        for (uint32_t i = lane; i < a.qpad; i += 64) qs[stored_pos(i)] = i < a.g.d ? q[i] : 0.0f;
+        for (uint32_t i = lane; i < a.qpad; i += 64) qs[U8 ? stored_pos_u8(i) : stored_pos(i)] = i < a.g.d ? q[i] : 0.0f;
         for (uint32_t i = lane; i < H; i += 64) hash[i] = kEmpty;
     }
     LDS_SYNC();
@@ -517,10 +607,10 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
     float cur_dist;
     if (lane == 0) visited_insert(hash, hmask, hshift, cur_id);
     {
-        const float* row[RM::kSub]; bool act[RM::kSub]; float dj[RM::kSub];
+        uint32_t rid[RM::kSub]; bool act[RM::kSub]; float dj[RM::kSub];
 #pragma unroll
-        for (int s = 0; s < RM::kSub; s++) { row[s] = vectors + (size_t)cur_id * row_stride + lane_off; act[s] = s == 0 && lane < RM::kLanesPerRow; }
-        batch_distance<SCALAR>(dc, row, act, dj, lane);
+        for (int s = 0; s < RM::kSub; s++) { rid[s] = cur_id; act[s] = s == 0 && lane < RM::kLanesPerRow; }
+        rows_distance<SCALAR, U8>(a.g, dc, rid, act, dj, lane);
         cur_dist = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(dj[0]), 0));
     }
     st.n_dist = 1;
@@ -549,13 +639,10 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
                 st.n_dist += m; nvis += m;
                 LDS_SYNC();
                 if (m == 0) continue;
-                const float* row[RM::kSub]; bool act[RM::kSub]; float dj[RM::kSub];
+                uint32_t rid[RM::kSub]; bool act[RM::kSub]; float dj[RM::kSub];
 #pragma unroll
-                for (int s = 0; s < RM::kSub; s++) {
-                    row[s] = vectors + (size_t)BL::spread(my_order, s) * row_stride + lane_off;
-                    act[s] = BL::spread((uint32_t)fresh, s) != 0;
-                }
-                batch_distance<SCALAR>(dc, row, act, dj, lane);
+                for (int s = 0; s < RM::kSub; s++) { rid[s] = BL::spread(my_order, s); act[s] = BL::spread((uint32_t)fresh, s) != 0; }
+                rows_distance<SCALAR, U8>(a.g, dc, rid, act, dj, lane);
                 const float dm = (!SCALAR && (lane & 3) == 1) ? dj[RM::kSub - 1] : dj[0];      // merged form
                 const bool mine = fresh && dm == dm;
                 const uint32_t key = mine ? __float_as_uint(dm) : 0x7F800000u;     // non-negative floats order as their bit patterns
@@ -627,13 +714,10 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
                 DIAG_STAMP(t2);
                 DIAG_ADD(cy_adj, t1b, t2);
                 if (m != 0) {
-                    const float* row[RM::kSub]; bool act[RM::kSub]; float dj[RM::kSub];
+                    uint32_t rid[RM::kSub]; bool act[RM::kSub]; float dj[RM::kSub];
 #pragma unroll
-                    for (int s = 0; s < RM::kSub; s++) {
-                        row[s] = vectors + (size_t)BL::spread(my, s) * row_stride + lane_off;
-                        act[s] = BL::spread((uint32_t)fresh, s) != 0;
-                    }
-                    batch_distance<SCALAR>(dc, row, act, dj, lane);
+                    for (int s = 0; s < RM::kSub; s++) { rid[s] = BL::spread(my, s); act[s] = BL::spread((uint32_t)fresh, s) != 0; }
+                    rows_distance<SCALAR, U8>(a.g, dc, rid, act, dj, lane);
                     const float dm = (!SCALAR && (lane & 3) == 1) ? dj[RM::kSub - 1] : dj[0];      // merged form
                     DIAG_STAMP(t3);
                     DIAG_ADD(cy_dist, t2, t3);
@@ -812,6 +896,25 @@ __global__ void store_rows_kernel(const float* __restrict__ src, float* __restri
     }
 }
 
+// The byte table, and whether it is exact: *bad is raised if any value is not an integer in 0..255.
+__global__ void store_rows_u8_kernel(const float* __restrict__ src, uint8_t* __restrict__ dst, uint32_t rows, uint32_t d, uint32_t row_stride_u8,
+                                     uint32_t* __restrict__ bad)
+{
+    const size_t total = (size_t)rows * row_stride_u8;
+    bool any_bad = false;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t row = (uint32_t)(i / row_stride_u8), dim = (uint32_t)(i % row_stride_u8);
+        uint8_t b = 0;
+        if (dim < d) {
+            const float v = src[(size_t)row * d + dim];
+            b = (uint8_t)(v >= 0.0f && v <= 255.0f ? (int)v : 0);
+            if (!((float)b == v)) any_bad = true;
+        }
+        dst[(size_t)row * row_stride_u8 + stored_pos_u8(dim)] = b;
+    }
+    if (any_bad) atomicOr(bad, 1u);
+}
+
 }  // namespace
 
 size_t search_lds_bytes(const SearchArgs& a, bool w_in_lds)
@@ -865,6 +968,15 @@ void DeviceIndex::upload(const HostIndex& h, int dev)
         HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&dv), bytes));
         bufs_[0] = dv;
         const uint32_t slab = (uint32_t)std::max<size_t>(1, std::min<size_t>(g.n, ((size_t)64 << 20) / g.d));
+        // second copy, one byte per dim; kept only if it is exact (every value an integer in 0..255)
+        g.row_stride_u8 = (g.d + 127u) & ~127u;
+        uint8_t* du = nullptr;
+        HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&du), (size_t)g.n * g.row_stride_u8));
+        bufs_[6] = du;
+        uint32_t* d_bad = nullptr;
+        HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_bad), 4));
+        bufs_[7] = d_bad;
+        HIP_CHECK(hipMemset(d_bad, 0, 4));
         float* tmp = nullptr;
         HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&tmp), (size_t)slab * g.d * sizeof(float)));
         for (uint32_t r0 = 0; r0 < g.n; r0 += slab) {
@@ -872,6 +984,8 @@ void DeviceIndex::upload(const HostIndex& h, int dev)
             hipError_t e = hipMemcpy(tmp, h.vector_data_.data() + (size_t)r0 * g.d, (size_t)rows * g.d * sizeof(float), hipMemcpyHostToDevice);
             if (e == hipSuccess) {
                 hipLaunchKernelGGL(store_rows_kernel, dim3(4096), dim3(256), 0, 0, tmp, dv + (size_t)r0 * g.row_stride, rows, g.d, g.row_stride);
+                hipLaunchKernelGGL(store_rows_u8_kernel, dim3(4096), dim3(256), 0, 0, tmp, du + (size_t)r0 * g.row_stride_u8, rows, g.d,
+                                   g.row_stride_u8, d_bad);
                 e = hipGetLastError();
             }
             if (e == hipSuccess) e = hipDeviceSynchronize();
@@ -879,6 +993,11 @@ void DeviceIndex::upload(const HostIndex& h, int dev)
         }
         HIP_CHECK(hipFree(tmp));
         g.vectors = dv;
+        uint32_t bad = 1;
+        HIP_CHECK(hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipFree(d_bad)); bufs_[7] = nullptr;
+        if (bad) { HIP_CHECK(hipFree(du)); bufs_[6] = nullptr; du = nullptr; }
+        g.vectors_u8 = du;
     }
     g.adj0 = to_device(fg.adj0, bufs_[1]);
     g.up_off = to_device(fg.up_off, bufs_[2]);
@@ -925,7 +1044,11 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
     a.g = g; a.queries = d_queries; a.qmap = nullptr; a.nq_launch = nq;
     a.ef = (uint32_t)ef; a.out_k = out_k; a.flags = flags;
     a.cap_w = ((uint32_t)ef + 2u) & ~1u;
-    a.qpad = (g.d + 63u) & ~63u;
+    const bool u8 = (flags & HNSW_AMD_ROWS_U8) != 0;
+    if (u8 && (flags & HNSW_AMD_DIST_SCALAR)) throw std::invalid_argument("search: HNSW_AMD_ROWS_U8 goes with HNSW_AMD_DIST_SSE only");
+    if (u8 && !g.vectors_u8)
+        throw std::invalid_argument("search: HNSW_AMD_ROWS_U8 needs base vectors whose values are all integers in 0..255");
+    a.qpad = u8 ? ((g.d + 127u) & ~127u) : ((g.d + 63u) & ~63u);
     a.out_ids = d_ids; a.out_dist = d_dist; a.out_count = d_count; a.stats = d_stats;
     const bool scalar = (flags & HNSW_AMD_DIST_SCALAR) != 0;
 
@@ -953,8 +1076,10 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
         a.fail_count = cur; a.fail_list = cur + 1;
         HIP_CHECK(hipMemsetAsync(cur, 0, 4, stream));
         void (*kern)(SearchArgs);
-        if (scalar) kern = std_heap ? hnsw_search_kernel<true, 0> : (ef <= 64 ? hnsw_search_kernel<true, 1> : (ef <= 128 ? hnsw_search_kernel<true, 2> : hnsw_search_kernel<true, 4>));
-        else kern = std_heap ? hnsw_search_kernel<false, 0> : (ef <= 64 ? hnsw_search_kernel<false, 1> : (ef <= 128 ? hnsw_search_kernel<false, 2> : hnsw_search_kernel<false, 4>));
+        const int wr = std_heap ? 0 : (ef <= 64 ? 1 : (ef <= 128 ? 2 : 4));
+        if (scalar) kern = wr == 0 ? hnsw_search_kernel<true, 0, false> : (wr == 1 ? hnsw_search_kernel<true, 1, false> : (wr == 2 ? hnsw_search_kernel<true, 2, false> : hnsw_search_kernel<true, 4, false>));
+        else if (u8) kern = wr == 0 ? hnsw_search_kernel<false, 0, true> : (wr == 1 ? hnsw_search_kernel<false, 1, true> : (wr == 2 ? hnsw_search_kernel<false, 2, true> : hnsw_search_kernel<false, 4, true>));
+        else kern = wr == 0 ? hnsw_search_kernel<false, 0, false> : (wr == 1 ? hnsw_search_kernel<false, 1, false> : (wr == 2 ? hnsw_search_kernel<false, 2, false> : hnsw_search_kernel<false, 4, false>));
         if (lds > 32768)
             HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         if (const char* pad = getenv("HNSW_AMD_LDS_PAD")) lds += (size_t)atoi(pad);      // occupancy experiments

@@ -27,11 +27,12 @@ def reference_precision(ids: np.ndarray, gt: np.ndarray, k: int = 10) -> float:
     return float(hit) / (ids.shape[0] * k)
 
 
-def algorithmic_bytes(stats: np.ndarray, d: int, d_used: int, k: int) -> np.ndarray:
-    """Bytes a query must move, independent of layout: one row of d_used floats per distance,
-    4 bytes per neighbour id of every list read, the query itself, the result."""
+def algorithmic_bytes(stats: np.ndarray, d: int, d_used: int, k: int, row_elem_bytes: int = 4) -> np.ndarray:
+    """Bytes a query must move, independent of layout: one row of d_used elements per distance
+    (floats; bytes when the byte-row table is searched), 4 bytes per neighbour id of every list
+    read, the query itself, the result."""
     s = stats
-    return (s["n_dist"].astype(np.int64) * 4 * d_used + 4 * (s["sum_deg0"].astype(np.int64) + s["sum_degu"])
+    return (s["n_dist"].astype(np.int64) * row_elem_bytes * d_used + 4 * (s["sum_deg0"].astype(np.int64) + s["sum_degu"])
             + 4 * d + 8 * k)
 
 

@@ -46,6 +46,12 @@ enum {
     HNSW_AMD_KEYS_INT32 = 0,      /* candidate heap keyed by int32-truncated distances, as the reference
                                      (src/hnsw.cpp:727,767) */
     HNSW_AMD_KEYS_FLOAT = 2,      /* candidate heap keyed by the float distance (textbook HNSW; not the reference) */
+    HNSW_AMD_ROWS_U8 = 8,         /* read the base vectors from a one-byte-per-dimension copy (4x fewer bytes gathered).
+                                     Only for an index whose stored values are all integers in 0..255 (SIFT, image
+                                     pixels): float(byte) is then the stored float exactly and every result is
+                                     unchanged.  HNSW_AMD_E_ARG otherwise, and with HNSW_AMD_DIST_SCALAR.  The
+                                     reference sketched byte vectors under COMPUTE_APPROXIMATE_VECTOR
+                                     (src/hnsw.cpp:451-467, aprDistance src/hnsw.h:455-467), lossy and disabled. */
     HNSW_AMD_W_STD_HEAP = 4       /* keep the result list W_ as the libstdc++ binary heap the reference keeps
                                      (src/hnsw.cpp:770-775), so that when several entries tie for the worst
                                      distance the one dropped is the reference's choice as well.  Default (flag

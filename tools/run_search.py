@@ -21,6 +21,7 @@ ap.add_argument("--threads", type=int, default=16)
 ap.add_argument("--cache", default="")
 ap.add_argument("--kind", default="sift")
 ap.add_argument("--keys", default="int32")
+ap.add_argument("--rows", default="f32", choices=["f32", "u8"])
 a = ap.parse_args()
 base = datagen.make(a.kind, a.n, seed=1)
 q = datagen.make(a.kind, a.nq, seed=1, stream=1)
@@ -36,7 +37,7 @@ h.sync_device(0)
 for rep in range(a.reps):
     t = time.time()
     from hnsw_amd import capi
-    h.flags = capi.DIST_SSE | (capi.KEYS_FLOAT if a.keys == "float" else capi.KEYS_INT32)
+    h.flags = capi.DIST_SSE | (capi.KEYS_FLOAT if a.keys == "float" else capi.KEYS_INT32) | (capi.ROWS_U8 if a.rows == "u8" else 0)
     ids, ds, cnt, st = h.search_batch(q, a.ef, out_k=10, stats=True)
     print(f"rep {rep}: host wall {1e3*(time.time()-t):.2f} ms", flush=True)
 print("n_dist/q", st["n_dist"].mean(), "expansions/q", st["n_expand"].mean())
