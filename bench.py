@@ -51,9 +51,10 @@ def main():
     ap.add_argument("--keys", default="int32", choices=["int32", "float"])
     ap.add_argument("--dist", default="sse", choices=["sse", "scalar"],
                     help="sse: the shipped reference's distance (first 16*floor(d/16) dims); scalar: its -DNO_MANUAL_VECTORIZATION build (all dims)")
-    ap.add_argument("--rows", default="f32", choices=["f32", "u8"],
+    ap.add_argument("--rows", default="f32", choices=["f32", "u8", "q8"],
                     help="u8: search the one-byte-per-dimension copy of the base (integer-valued data only; results unchanged); "
-                         "the algorithmic bytes are then counted at 1 byte per dimension")
+                         "q8: search a quantised byte copy of any base, the ef results re-scored with the float rows (approximate). "
+                         "The algorithmic bytes are then counted at 1 byte per dimension (4 for the re-scored rows)")
     ap.add_argument("--sweep", default="", help="comma-separated ef values: report recall and QPS for each instead of one operating point")
     args = ap.parse_args()
 
@@ -122,8 +123,8 @@ def main():
     cnt_t = torch.empty((nq,), dtype=torch.int32, device=dev)
     stats_t = torch.empty((nq, 8), dtype=torch.int32, device=dev)
     flags = (capi.DIST_SCALAR if args.dist == "scalar" else capi.DIST_SSE) | (capi.KEYS_FLOAT if args.keys == "float" else capi.KEYS_INT32)
-    flags |= capi.ROWS_U8 if args.rows == "u8" else 0
-    row_elem_bytes = 1 if args.rows == "u8" else 4
+    flags |= capi.ROWS_U8 if args.rows == "u8" else (capi.ROWS_Q8 if args.rows == "q8" else 0)
+    row_elem_bytes = 4 if args.rows == "f32" else 1
     h.flags = flags
     offsets = np.array([r * args.n // world for r in range(world)], dtype=np.uint32)
     out_ids = torch.empty((nq, k), dtype=torch.int32, device=dev)
@@ -181,6 +182,7 @@ def main():
                 st = stats_t.cpu().numpy().view(np.uint32).reshape(nq, 8).copy().view(capi.STATS_DTYPE).reshape(nq)
                 rec["dist_per_query"] = round(float(st["n_dist"].mean()), 1)
                 bpl = int(harness.algorithmic_bytes(st, d, d if args.dist == "scalar" else d & ~15, k, row_elem_bytes).sum())
+                bpl += 3 * ef * (d & ~15) * nq if args.rows == "q8" else 0      # the re-scored rows are float rows
             t0 = time.perf_counter()
             for _ in range(3):
                 step(ef, k)
@@ -222,6 +224,7 @@ def main():
     torch.cuda.synchronize()
     st = stats_t.cpu().numpy().view(np.uint32).reshape(nq, 8).copy().view(capi.STATS_DTYPE).reshape(nq)
     bytes_per_launch = int(harness.algorithmic_bytes(st, d, d if args.dist == "scalar" else d & ~15, k, row_elem_bytes).sum())
+    bytes_per_launch += 3 * ef * (d & ~15) * nq if args.rows == "q8" else 0      # the re-scored rows are float rows
     ids_final = out_ids.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
     # top-(k+1) for the reference's own "Precision" figure
     prec_ref = None

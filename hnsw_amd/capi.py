@@ -21,6 +21,7 @@ DIST_SSE, DIST_SCALAR = 0, 1
 KEYS_INT32, KEYS_FLOAT = 0, 2
 W_STD_HEAP = 4
 ROWS_U8 = 8
+ROWS_Q8 = 16
 
 _u32p = C.POINTER(C.c_uint32)
 _f32p = C.POINTER(C.c_float)

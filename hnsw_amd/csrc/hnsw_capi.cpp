@@ -61,9 +61,10 @@ static int guarded(F&& f)
 #define REQUIRE(cond, msg) do { if (!(cond)) throw std::invalid_argument(msg); } while (0)
 #define HIP_OK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) throw std::runtime_error(std::string("HIP: ") + #expr + ": " + hipGetErrorString(e_)); } while (0)
 
-static void ensure_device_copy(hnsw_amd_index* h)
+static void ensure_device_copy(hnsw_amd_index* h, uint32_t flags = 0)
 {
     if (h->dev.device != h->device || h->dev.version != h->host.version_) h->dev.upload(h->host, h->device);
+    if (flags & HNSW_AMD_ROWS_Q8) h->dev.ensure_quantized(h->host);
 }
 
 extern "C" {
@@ -126,7 +127,7 @@ int hnsw_amd_search_batch_device(hnsw_amd_index* h, const float* d_queries, uint
 {
     return guarded([&] {
         REQUIRE(h && d_queries && d_out_ids && d_out_dist, "search_batch_device: NULL argument");
-        ensure_device_copy(h);
+        ensure_device_copy(h, flags);
         uint32_t r = h->dev.search(d_queries, nq, ef, out_k, flags, d_out_ids, d_out_dist, d_out_count, d_stats, stream, true);
         if (retried) *retried = r;
     });
@@ -138,7 +139,7 @@ int hnsw_amd_search_batch(hnsw_amd_index* h, const float* queries, uint32_t nq, 
     return guarded([&] {
         REQUIRE(h && (queries || nq == 0) && out_ids && out_dist, "search_batch: NULL argument");
         if (nq == 0) return;
-        ensure_device_copy(h);
+        ensure_device_copy(h, flags);
         HIP_OK(hipSetDevice(h->device));
         const size_t qb = (size_t)nq * h->host.vector_size_ * sizeof(float);
         const size_t oe = (size_t)nq * out_k;

@@ -18,6 +18,8 @@ struct DeviceGraph {
     const float* vectors;       // n x row_stride floats, the dims of every 128-byte line regrouped by lane sum
     const uint8_t* vectors_u8;  // n x row_stride_u8 bytes, one per dim, or nullptr when some value is not an integer in 0..255
     uint32_t row_stride_u8;     // d rounded up to a multiple of 128
+    const uint8_t* vectors_q8;  // same shape: byte = clamp(round((v - q8_lo) * q8_inv_step), 0, 255); nullptr until asked for
+    float q8_lo, q8_inv_step;
     const uint32_t* adj0;       // n x deg0, 0xFFFFFFFF padded (the live entries are a prefix)
     const uint32_t* up_off;     // nlayers+1
     const uint32_t* up_down;    // U
@@ -65,6 +67,8 @@ public:
     ~DeviceIndex();
     void release();
     void upload(const HostIndex& h, int device);
+    // Builds the quantised byte table (HNSW_AMD_ROWS_Q8) on first use.
+    void ensure_quantized(const HostIndex& h);
     // Runs the batch (device pointers), re-running overflowed queries on larger tiers.
     // Returns the number of re-run queries; throws on HIP errors / scratch exhaustion.
     uint32_t search(const float* d_queries, uint32_t nq, int ef, uint32_t out_k, uint32_t flags, uint32_t* d_ids,

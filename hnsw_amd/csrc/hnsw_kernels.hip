@@ -512,16 +512,17 @@ __device__ __forceinline__ void batch_distance_u8(const DistCtx& c, const uint8_
 }
 
 // Distances to the rows `id[s]` (sub-batch s; act[s]: the lane's row takes part), from the float or the byte table.
-template <bool SCALAR, bool U8>
+template <bool SCALAR, int ROWS>
 __device__ __forceinline__ void rows_distance(const DeviceGraph& g, const DistCtx& c, const uint32_t (&id)[RowMap<SCALAR>::kSub],
                                               const bool (&act)[RowMap<SCALAR>::kSub], float (&out)[RowMap<SCALAR>::kSub], int lane)
 {
     typedef RowMap<SCALAR> RM;
-    if constexpr (U8) {
+    if constexpr (ROWS != 0) {
         static_assert(!SCALAR, "byte rows are read in SSE order only");
+        const uint8_t* const table = ROWS == 1 ? g.vectors_u8 : g.vectors_q8;
         const uint8_t* row[2];
 #pragma unroll
-        for (int s = 0; s < 2; s++) row[s] = g.vectors_u8 + (size_t)id[s] * g.row_stride_u8 + 32u * (lane & 3);
+        for (int s = 0; s < 2; s++) row[s] = table + (size_t)id[s] * g.row_stride_u8 + 32u * (lane & 3);
         batch_distance_u8(c, row, act, out, lane);
     } else {
         const float* row[RM::kSub];
@@ -561,8 +562,12 @@ struct BatchLanes {
 //         largest distance f and the size of W steer the search, and both evolve
 //         identically; the one observable difference is which of several entries with
 //         exactly the worst distance is dropped.
-// U8: rows are read from the byte table (DeviceGraph::vectors_u8) instead of the float table.
-template <bool SCALAR, int WR, bool U8>
+// ROWS = 0: rows are read from the float table.
+// ROWS = 1: from the exact byte table (DeviceGraph::vectors_u8): same arithmetic, same results.
+// ROWS = 2: from the quantised byte table (vectors_q8) with the query mapped to the same grid, so the
+//           search runs on approximate distances; its ef results are then re-scored with the exact
+//           float distance and sorted by it.
+template <bool SCALAR, int WR, int ROWS>
 __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
 {
     typedef RowMap<SCALAR> RM;
@@ -589,7 +594,11 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
     // query into LDS in stored form (zero padded), visited set empty
     {
         const float* q = a.queries + (size_t)qi * a.g.d;
-        for (uint32_t i = lane; i < a.qpad; i += 64) qs[U8 ? stored_pos_u8(i) : stored_pos(i)] = i < a.g.d ? q[i] : 0.0f;
+        for (uint32_t i = lane; i < a.qpad; i += 64) {
+            float v = i < a.g.d ? q[i] : 0.0f;
+            if (ROWS == 2 && i < a.g.d) v = (v - a.g.q8_lo) * a.g.q8_inv_step;
+            qs[ROWS != 0 ? stored_pos_u8(i) : stored_pos(i)] = v;
+        }
         for (uint32_t i = lane; i < H; i += 64) hash[i] = kEmpty;
     }
     LDS_SYNC();
@@ -610,7 +619,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
         uint32_t rid[RM::kSub]; bool act[RM::kSub]; float dj[RM::kSub];
 #pragma unroll
         for (int s = 0; s < RM::kSub; s++) { rid[s] = cur_id; act[s] = s == 0 && lane < RM::kLanesPerRow; }
-        rows_distance<SCALAR, U8>(a.g, dc, rid, act, dj, lane);
+        rows_distance<SCALAR, ROWS>(a.g, dc, rid, act, dj, lane);
         cur_dist = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(dj[0]), 0));
     }
     st.n_dist = 1;
@@ -642,7 +651,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
                 uint32_t rid[RM::kSub]; bool act[RM::kSub]; float dj[RM::kSub];
 #pragma unroll
                 for (int s = 0; s < RM::kSub; s++) { rid[s] = BL::spread(my_order, s); act[s] = BL::spread((uint32_t)fresh, s) != 0; }
-                rows_distance<SCALAR, U8>(a.g, dc, rid, act, dj, lane);
+                rows_distance<SCALAR, ROWS>(a.g, dc, rid, act, dj, lane);
                 const float dm = (!SCALAR && (lane & 3) == 1) ? dj[RM::kSub - 1] : dj[0];      // merged form
                 const bool mine = fresh && dm == dm;
                 const uint32_t key = mine ? __float_as_uint(dm) : 0x7F800000u;     // non-negative floats order as their bit patterns
@@ -717,7 +726,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
                     uint32_t rid[RM::kSub]; bool act[RM::kSub]; float dj[RM::kSub];
 #pragma unroll
                     for (int s = 0; s < RM::kSub; s++) { rid[s] = BL::spread(my, s); act[s] = BL::spread((uint32_t)fresh, s) != 0; }
-                    rows_distance<SCALAR, U8>(a.g, dc, rid, act, dj, lane);
+                    rows_distance<SCALAR, ROWS>(a.g, dc, rid, act, dj, lane);
                     const float dm = (!SCALAR && (lane & 3) == 1) ? dj[RM::kSub - 1] : dj[0];      // merged form
                     DIAG_STAMP(t3);
                     DIAG_ADD(cy_dist, t2, t3);
@@ -855,6 +864,27 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
             if ((uint32_t)(w * 64 + lane) < nW) W[w * 64 + lane] = make_uint2(wd[w], wi[w]);
         LDS_SYNC();
     }
+    if constexpr (ROWS == 2) {
+        // the search ran on the quantised table: replace every result's distance by the exact one
+        // (float rows, the reference's SSE order) before sorting
+        const float* q = a.queries + (size_t)qi * a.g.d;
+        const uint32_t qpad_f = (a.g.d + 63u) & ~63u;
+        for (uint32_t i = lane; i < qpad_f; i += 64) qs[stored_pos(i)] = i < a.g.d ? q[i] : 0.0f;
+        LDS_SYNC();
+        const DistCtx dx = make_dist_ctx<false>(qs, a.g.d);
+        for (uint32_t b0 = 0; b0 < nW; b0 += 32) {
+            const uint32_t e = b0 + mrow;                                 // merged form: lane 4r+s <-> entry b0 + 2r + s
+            const uint32_t my = e < nW ? W[e].y : kEmpty;
+            uint32_t rid[2]; bool act[2]; float dj[2];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; s2++) { rid[s2] = BL::spread(my, s2); act[s2] = rid[s2] != kEmpty; }
+            rows_distance<false, 0>(a.g, dx, rid, act, dj, lane);
+            const float dm = (lane & 3) == 1 ? dj[1] : dj[0];
+            if (my != kEmpty) W[e].x = __float_as_uint(dm);
+            st.n_dist += (uint32_t)__popcll(__ballot(my != kEmpty));
+        }
+        LDS_SYNC();
+    }
     for (uint32_t i = lane; i < nW; i += 64) {
         const uint2 me = W[i];
         uint32_t rank = 0;
@@ -913,6 +943,22 @@ __global__ void store_rows_u8_kernel(const float* __restrict__ src, uint8_t* __r
         dst[(size_t)row * row_stride_u8 + stored_pos_u8(dim)] = b;
     }
     if (any_bad) atomicOr(bad, 1u);
+}
+
+// The quantised byte table: byte = clamp(round((v - lo) * inv_step), 0, 255).
+__global__ void store_rows_q8_kernel(const float* __restrict__ src, uint8_t* __restrict__ dst, uint32_t rows, uint32_t d, uint32_t row_stride_u8,
+                                     float lo, float inv_step)
+{
+    const size_t total = (size_t)rows * row_stride_u8;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t row = (uint32_t)(i / row_stride_u8), dim = (uint32_t)(i % row_stride_u8);
+        uint8_t b = 0;
+        if (dim < d) {
+            const float t = rintf((src[(size_t)row * d + dim] - lo) * inv_step);
+            b = (uint8_t)(t <= 0.0f ? 0 : (t >= 255.0f ? 255 : (int)t));
+        }
+        dst[(size_t)row * row_stride_u8 + stored_pos_u8(dim)] = b;
+    }
 }
 
 }  // namespace
@@ -1009,6 +1055,47 @@ void DeviceIndex::upload(const HostIndex& h, int dev)
     hint_tier = 0; hint_ef = 0; hint_flags = 0;
 }
 
+void DeviceIndex::ensure_quantized(const HostIndex& h)
+{
+    if (device < 0) throw std::logic_error("ensure_quantized: index not on a device");
+    if (g.vectors_q8) return;
+    HIP_CHECK(hipSetDevice(device));
+    // One grid for the whole table: [lo, hi] = the 0.1 % and 99.9 % quantiles of a sample of the stored
+    // values (outliers are clamped), 255 steps in between.
+    const size_t total = (size_t)g.n * g.d;
+    const size_t want = std::min<size_t>(total, (size_t)1 << 20);
+    std::vector<float> sample(want);
+    const size_t stride = total / want;
+    for (size_t i = 0; i < want; i++) sample[i] = h.vector_data_[i * stride];
+    const size_t klo = want / 1000, khi = want - 1 - want / 1000;
+    std::nth_element(sample.begin(), sample.begin() + klo, sample.end());
+    const float lo = sample[klo];
+    std::nth_element(sample.begin(), sample.begin() + khi, sample.end());
+    float hi = sample[khi];
+    if (!(hi > lo)) hi = lo + 1.0f;
+    const float step = (hi - lo) / 255.0f;
+    uint8_t* dq = nullptr;
+    HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&dq), (size_t)g.n * g.row_stride_u8));
+    bufs_[7] = dq;
+    const uint32_t slab = (uint32_t)std::max<size_t>(1, std::min<size_t>(g.n, ((size_t)64 << 20) / g.d));
+    float* tmp = nullptr;
+    HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&tmp), (size_t)slab * g.d * sizeof(float)));
+    for (uint32_t r0 = 0; r0 < g.n; r0 += slab) {
+        const uint32_t rows = std::min(slab, g.n - r0);
+        hipError_t e = hipMemcpy(tmp, h.vector_data_.data() + (size_t)r0 * g.d, (size_t)rows * g.d * sizeof(float), hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(store_rows_q8_kernel, dim3(4096), dim3(256), 0, 0, tmp, dq + (size_t)r0 * g.row_stride_u8, rows, g.d,
+                               g.row_stride_u8, lo, 1.0f / step);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e != hipSuccess) { (void)hipFree(tmp); HIP_CHECK(e); }
+    }
+    HIP_CHECK(hipFree(tmp));
+    g.q8_lo = lo; g.q8_inv_step = 1.0f / step;
+    g.vectors_q8 = dq;
+}
+
 static ScratchTier tier_for(int ef, int tier)
 {
     // Sized from measured search statistics (visited ~ 16-25 x ef on graphs of 10^4..10^6
@@ -1044,11 +1131,14 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
     a.g = g; a.queries = d_queries; a.qmap = nullptr; a.nq_launch = nq;
     a.ef = (uint32_t)ef; a.out_k = out_k; a.flags = flags;
     a.cap_w = ((uint32_t)ef + 2u) & ~1u;
+    const bool q8 = (flags & HNSW_AMD_ROWS_Q8) != 0;
     const bool u8 = (flags & HNSW_AMD_ROWS_U8) != 0;
-    if (u8 && (flags & HNSW_AMD_DIST_SCALAR)) throw std::invalid_argument("search: HNSW_AMD_ROWS_U8 goes with HNSW_AMD_DIST_SSE only");
+    if ((u8 || q8) && (flags & HNSW_AMD_DIST_SCALAR)) throw std::invalid_argument("search: byte rows go with HNSW_AMD_DIST_SSE only");
+    if (u8 && q8) throw std::invalid_argument("search: HNSW_AMD_ROWS_U8 and HNSW_AMD_ROWS_Q8 exclude each other");
     if (u8 && !g.vectors_u8)
         throw std::invalid_argument("search: HNSW_AMD_ROWS_U8 needs base vectors whose values are all integers in 0..255");
-    a.qpad = u8 ? ((g.d + 127u) & ~127u) : ((g.d + 63u) & ~63u);
+    if (q8 && !g.vectors_q8) throw std::logic_error("search: the quantised table was not built");
+    a.qpad = (u8 || q8) ? ((g.d + 127u) & ~127u) : ((g.d + 63u) & ~63u);
     a.out_ids = d_ids; a.out_dist = d_dist; a.out_count = d_count; a.stats = d_stats;
     const bool scalar = (flags & HNSW_AMD_DIST_SCALAR) != 0;
 
@@ -1077,9 +1167,10 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
         HIP_CHECK(hipMemsetAsync(cur, 0, 4, stream));
         void (*kern)(SearchArgs);
         const int wr = std_heap ? 0 : (ef <= 64 ? 1 : (ef <= 128 ? 2 : 4));
-        if (scalar) kern = wr == 0 ? hnsw_search_kernel<true, 0, false> : (wr == 1 ? hnsw_search_kernel<true, 1, false> : (wr == 2 ? hnsw_search_kernel<true, 2, false> : hnsw_search_kernel<true, 4, false>));
-        else if (u8) kern = wr == 0 ? hnsw_search_kernel<false, 0, true> : (wr == 1 ? hnsw_search_kernel<false, 1, true> : (wr == 2 ? hnsw_search_kernel<false, 2, true> : hnsw_search_kernel<false, 4, true>));
-        else kern = wr == 0 ? hnsw_search_kernel<false, 0, false> : (wr == 1 ? hnsw_search_kernel<false, 1, false> : (wr == 2 ? hnsw_search_kernel<false, 2, false> : hnsw_search_kernel<false, 4, false>));
+        if (scalar) kern = wr == 0 ? hnsw_search_kernel<true, 0, 0> : (wr == 1 ? hnsw_search_kernel<true, 1, 0> : (wr == 2 ? hnsw_search_kernel<true, 2, 0> : hnsw_search_kernel<true, 4, 0>));
+        else if (u8) kern = wr == 0 ? hnsw_search_kernel<false, 0, 1> : (wr == 1 ? hnsw_search_kernel<false, 1, 1> : (wr == 2 ? hnsw_search_kernel<false, 2, 1> : hnsw_search_kernel<false, 4, 1>));
+        else if (q8) kern = wr == 0 ? hnsw_search_kernel<false, 0, 2> : (wr == 1 ? hnsw_search_kernel<false, 1, 2> : (wr == 2 ? hnsw_search_kernel<false, 2, 2> : hnsw_search_kernel<false, 4, 2>));
+        else kern = wr == 0 ? hnsw_search_kernel<false, 0, 0> : (wr == 1 ? hnsw_search_kernel<false, 1, 0> : (wr == 2 ? hnsw_search_kernel<false, 2, 0> : hnsw_search_kernel<false, 4, 0>));
         if (lds > 32768)
             HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         if (const char* pad = getenv("HNSW_AMD_LDS_PAD")) lds += (size_t)atoi(pad);      // occupancy experiments

@@ -52,6 +52,12 @@ enum {
                                      unchanged.  HNSW_AMD_E_ARG otherwise, and with HNSW_AMD_DIST_SCALAR.  The
                                      reference sketched byte vectors under COMPUTE_APPROXIMATE_VECTOR
                                      (src/hnsw.cpp:451-467, aprDistance src/hnsw.h:455-467), lossy and disabled. */
+    HNSW_AMD_ROWS_Q8 = 16,        /* search a quantised one-byte-per-dimension copy of ANY base (one grid of 256 levels
+                                     between the 0.1 % and 99.9 % quantiles of the stored values), the query mapped
+                                     to the same grid; the ef results are then re-scored with the exact float
+                                     distance and sorted by it.  4x fewer bytes gathered; an approximation of the
+                                     reference's search, not a reproduction (the idea the reference left disabled,
+                                     see HNSW_AMD_ROWS_U8).  With HNSW_AMD_DIST_SSE only. */
     HNSW_AMD_W_STD_HEAP = 4       /* keep the result list W_ as the libstdc++ binary heap the reference keeps
                                      (src/hnsw.cpp:770-775), so that when several entries tie for the worst
                                      distance the one dropped is the reference's choice as well.  Default (flag

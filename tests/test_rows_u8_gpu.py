@@ -59,3 +59,29 @@ def test_byte_rows_refused_for_other_data():
     with pytest.raises(capi.HnswAmdError) as e:
         h2.search_batch(ints[:5], 20, flags=capi.DIST_SCALAR | capi.ROWS_U8)
     assert e.value.code == capi.E_ARG
+
+
+@pytest.mark.parametrize("kind,n,ef", [("glove", 40000, 60), ("deep", 40000, 60), ("sift", 40000, 50), ("gist", 6000, 64)])
+def test_quantised_rows_search_then_exact_rescoring(kind, n, ef):
+    """HNSW_AMD_ROWS_Q8 is an approximation of the reference's search (never used for parity): what is
+    checked is that the reported distances are the exact float distances of the reported ids, in order,
+    and that recall against exact brute force stays close to the float-row search's."""
+    from oracle import oracle
+    from tests.helpers import recall_at_k
+    nq, k = 300, 10
+    base = datagen.make(kind, n, seed=8)
+    q = datagen.make(kind, nq, seed=8, stream=1)
+    d = base.shape[1]
+    used = d & ~15
+    h = HNSW(16, 16, 100)
+    h.init(d, n)
+    h.insert_batch(base, threads=16)
+    ids_f, dist_f, _ = h.search_batch(q, ef, flags=capi.DIST_SSE | capi.KEYS_FLOAT)
+    ids_q, dist_q, cnt_q = h.search_batch(q, ef, flags=capi.DIST_SSE | capi.KEYS_FLOAT | capi.ROWS_Q8)
+    assert (cnt_q == ef).all() and (ids_q < n).all()
+    assert (np.diff(dist_q, axis=1) >= 0).all()
+    exact = ((q[:, None, :used].astype(np.float64) - base[ids_q][:, :, :used].astype(np.float64)) ** 2).sum(-1)
+    assert np.allclose(dist_q, exact, rtol=1e-5, atol=1e-6)
+    gt = oracle.bruteforce(base[:, :used], q[:, :used], k, threads=8)
+    r_f, r_q = recall_at_k(ids_f[:, :k], gt, k), recall_at_k(ids_q[:, :k], gt, k)
+    assert r_q >= r_f - 0.03, (r_f, r_q)
