@@ -55,6 +55,10 @@ def main():
                     help="u8: search the one-byte-per-dimension copy of the base (integer-valued data only; results unchanged); "
                          "q8: search a quantised byte copy of any base, the ef results re-scored with the float rows (approximate). "
                          "The algorithmic bytes are then counted at 1 byte per dimension (4 for the re-scored rows)")
+    ap.add_argument("--mode", default="sharded", choices=["sharded", "replicated"],
+                    help="N > 1: sharded = the base split into N sub-graphs, every query on every GPU, all-gather + merge "
+                         "(fixed total work); replicated = the whole index on every GPU, each with its own batch of "
+                         "--queries queries and no collective in the data path (work grows with N)")
     ap.add_argument("--sweep", default="", help="comma-separated ef values: report recall and QPS for each instead of one operating point")
     args = ap.parse_args()
 
@@ -84,17 +88,20 @@ def main():
     d = datagen.KINDS[args.kind]
     k = args.k
     # ---- shard of the base set, queries ----
-    lo = rank * args.n // world
-    hi = (rank + 1) * args.n // world
+    parts = world if args.mode == "sharded" else 1        # sub-graphs the base is split into
+    prank = rank if args.mode == "sharded" else 0
+    lo = prank * args.n // parts
+    hi = (prank + 1) * args.n // parts
     t0 = time.time()
     base = datagen.make(args.kind, hi - lo, seed=1, stream=0, row0=lo)
-    queries = datagen.make(args.kind, args.nq, seed=1, stream=1)
+    # replicated: every rank has its own batch of queries (rows rank*nq .. of the query stream)
+    queries = datagen.make(args.kind, args.nq, seed=1, stream=1, row0=0 if parts == world else rank * args.nq)
     log(f"rank {rank}: data {base.shape} in {time.time() - t0:.1f}s")
 
     # ---- build (host, concurrent inserts) or load from the cache directory ----
     h = HNSW(16, 16, 200, device=local_rank)
     cache = os.environ.get("HNSW_AMD_BENCH_CACHE")
-    cpath = os.path.join(cache, f"{args.kind}_n{args.n}_s{world}_r{rank}.npz") if cache else None
+    cpath = os.path.join(cache, f"{args.kind}_n{args.n}_s{parts}_r{prank}.npz") if cache else None
     t0 = time.time()
     if cpath and os.path.exists(cpath):
         from hnsw_amd.flatgraph import FlatGraph
@@ -126,23 +133,23 @@ def main():
     flags |= capi.ROWS_U8 if args.rows == "u8" else (capi.ROWS_Q8 if args.rows == "q8" else 0)
     row_elem_bytes = 4 if args.rows == "f32" else 1
     h.flags = flags
-    offsets = np.array([r * args.n // world for r in range(world)], dtype=np.uint32)
+    offsets = np.array([r * args.n // parts for r in range(parts)], dtype=np.uint32)
     out_ids = torch.empty((nq, k), dtype=torch.int32, device=dev)
     out_dist = torch.empty((nq, k), dtype=torch.float32, device=dev)
     L = capi.lib()
 
     from hnsw_amd.sharded import ShardedHNSW
     sh = ShardedHNSW.__new__(ShardedHNSW)      # wrap the index built above
-    sh.n_total, sh.d, sh.rank, sh.world, sh.lo, sh.hi = args.n, d, rank, world, lo, hi
+    sh.n_total, sh.d, sh.rank, sh.world, sh.lo, sh.hi = args.n, d, prank, parts, lo, hi
     sh.offsets, sh.group, sh.index = offsets, None, h
 
     def step(ef, out_k, want_stats=False):
         """One pass over the query batch; leaves the final top-out_k (global ids) in out_ids/out_dist."""
         stream = torch.cuda.current_stream().cuda_stream
-        if world == 1 or want_stats:
+        if parts == 1 or want_stats:
             h.search_batch_device(q_t.data_ptr(), nq, ef, out_k, out_ids.data_ptr(), out_dist.data_ptr(), cnt_t.data_ptr(),
                                   stats_t.data_ptr() if want_stats else 0, stream, flags)
-            if world == 1:
+            if parts == 1:
                 return
         i_t, d_t = sh.search(q_t, ef, out_k)
         out_ids.copy_(i_t); out_dist.copy_(d_t)
@@ -150,17 +157,17 @@ def main():
     # ---- exact ground truth (brute force on the GPU over every shard, merged) ----
     t0 = time.time()
     base_t = torch.from_numpy(base).to(dev)
-    gd, gi, gt_info = harness.exact_topk_mfma(base_t, q_t, k + 1, id_offset=int(offsets[rank]))
+    gd, gi, gt_info = harness.exact_topk_mfma(base_t, q_t, k + 1, id_offset=int(offsets[prank]))
     del base_t
     # cross-check of the ground truth on a sample: CPU scan in double precision (N=1 only: needs the whole base)
-    if world == 1:
+    if parts == 1 and rank == 0:
         from oracle import oracle as _oracle
         samp = np.linspace(0, args.nq - 1, 16).astype(int)
         cpu_gt = _oracle.bruteforce(base, queries[samp], k, threads=min(16, os.cpu_count() or 1)).astype(np.int64)
         gsub = gi[torch.from_numpy(samp).to(dev)].cpu().numpy()[:, :k]
         dd = lambda ids: ((queries[samp][:, None, :].astype(np.float64) - base[ids].astype(np.float64)) ** 2).sum(-1)
         gt_info["cpu_double_check"] = bool(np.array_equal(dd(gsub), dd(cpu_gt)))    # same distances: equal up to exact ties
-    if world > 1:
+    if parts > 1:
         all_d = [torch.empty_like(gd) for _ in range(world)]
         all_i = [torch.empty_like(gi) for _ in range(world)]
         dist.all_gather(all_d, gd)
@@ -174,11 +181,11 @@ def main():
     if args.sweep:
         rows = []
         for ef in [int(x) for x in args.sweep.split(",")]:
-            step(ef, k, want_stats=(world == 1))
+            step(ef, k, want_stats=(parts == 1))
             torch.cuda.synchronize()
             ids = out_ids.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
             rec = {"ef": ef, "recall_at_10": round(harness.recall_at_k(ids, gt, k), 4)}
-            if world == 1:
+            if parts == 1:
                 st = stats_t.cpu().numpy().view(np.uint32).reshape(nq, 8).copy().view(capi.STATS_DTYPE).reshape(nq)
                 rec["dist_per_query"] = round(float(st["n_dist"].mean()), 1)
                 bpl = int(harness.algorithmic_bytes(st, d, d if args.dist == "scalar" else d & ~15, k, row_elem_bytes).sum())
@@ -189,7 +196,7 @@ def main():
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / 3
             rec["qps"] = round(nq / dt, 1)
-            if world == 1:
+            if parts == 1:
                 rec["algorithmic_gbs"] = round(bpl / dt / 1e9, 1)
             rows.append(rec)
             log(f"sweep {rec}")
@@ -204,7 +211,7 @@ def main():
     sweep = []
     ef_pick = args.ef
     # shards see fewer points each, so a sharded run may reach the target below the reference's first value (20)
-    sweep_values = harness.REFERENCE_EF_SWEEP if world == 1 else [10, 12, 14, 16, 18] + harness.REFERENCE_EF_SWEEP
+    sweep_values = harness.REFERENCE_EF_SWEEP if parts == 1 else [10, 12, 14, 16, 18] + harness.REFERENCE_EF_SWEEP
     for ef in ([args.ef] if args.ef else sweep_values):
         step(ef, k)
         torch.cuda.synchronize()
@@ -228,7 +235,7 @@ def main():
     ids_final = out_ids.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
     # top-(k+1) for the reference's own "Precision" figure
     prec_ref = None
-    if world == 1:
+    if parts == 1:
         kk_ids = torch.empty((nq, k + 1), dtype=torch.int32, device=dev)
         kk_d = torch.empty((nq, k + 1), dtype=torch.float32, device=dev)
         h.search_batch_device(q_t.data_ptr(), nq, max(ef, k + 1), k + 1, kk_ids.data_ptr(), kk_d.data_ptr(), 0, 0,
@@ -236,6 +243,16 @@ def main():
         torch.cuda.synchronize()
         prec_ref = harness.reference_precision(kk_ids.cpu().numpy().astype(np.int64) & 0xFFFFFFFF, gt, k)
     recall = harness.recall_at_k(ids_final, gt, k)
+    if world > 1 and parts == 1:
+        # replicated: every rank picked its operating point on its own queries; they must agree, and the
+        # reported recall is the mean over ranks
+        rt = torch.tensor([recall, float(ef), -float(ef)], dtype=torch.float64, device=dev)
+        mx = rt.clone()
+        dist.all_reduce(rt, op=dist.ReduceOp.SUM)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        if mx[1].item() != -mx[2].item():
+            raise SystemExit("replicated ranks chose different ef values: pass --ef")
+        recall = float(rt[0].item()) / world
 
     # ---- timed region ----
     log(f"rank {rank}: operating point ef={ef} recall@10={recall:.4f}; timing {args.steps} steps")
@@ -262,11 +279,11 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     ms_per_step = elapsed / args.steps * 1e3
-    qps = nq * args.steps / elapsed
+    qps = nq * (world if parts == 1 else 1) * args.steps / elapsed
     log(f"rank {rank}: {ms_per_step:.3f} ms/step")
 
     # search-kernel time alone (events around the search call only; N=1: the whole step)
-    if world == 1:
+    if parts == 1:
         kern_ms = step_ms_dev
     else:
         kev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
@@ -369,9 +386,10 @@ def main():
             "metric": "queries/s at recall@10>=0.95, HNSW search, SIFT-128-shaped 1M base / 10k queries",
             "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong" if parts > 1 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.kind}-{d} synthetic, n={args.n}, nq={nq}, M=16, efConstruction=200, ef={ef}, k={k}, "
-                                   f"keys={args.keys}, rows={args.rows}" + (f", {world} shards + RCCL all-gather + device merge" if world > 1 else ""),
+                                   f"keys={args.keys}, rows={args.rows}" + (f", {world} shards + RCCL all-gather + device merge" if parts > 1 else "")
+                                   + (f", index replicated on {world} GPUs, {nq} queries each" if world > 1 and parts == 1 else ""),
                        "ef": ef, "recall_at_10": round(recall, 4), "reference_precision_top11": prec_ref,
                        "ef_sweep": sweep, "build_s": round(build_s, 1), "build_threads": args.build_threads,
                        "ground_truth": dict(gt_info, method="exact brute force, f32-input MFMA kernel of this library")},

@@ -76,14 +76,41 @@ __global__ __launch_bounds__(256) void dist_tile_kernel(const float* __restrict_
     // compute role
     const int fi = lane & 31, fk = lane >> 5;
 
+    // The 16 + 16 values of the next k step are fetched into registers while the matrix cores work on
+    // the current one (16-byte loads when the rows allow it).
+    float ra[16], rb[16];
+    const bool vec = (d & 3u) == 0;
+    auto fetch = [&](uint32_t k0) {
+        const uint32_t kb = k0 + 16 * kh;
+        if (vec) {
+#pragma unroll
+            for (int j = 0; j < 16; j += 4) {
+                float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
+                if (kb + j < d) {                       // d % 4 == 0: a group of 4 is inside the row or outside it
+                    if (qok) va = *reinterpret_cast<const float4*>(qp + kb + j);
+                    if (xok) vb = *reinterpret_cast<const float4*>(xp + kb + j);
+                }
+                ra[j] = va.x; ra[j + 1] = va.y; ra[j + 2] = va.z; ra[j + 3] = va.w;
+                rb[j] = vb.x; rb[j + 1] = vb.y; rb[j + 2] = vb.z; rb[j + 3] = vb.w;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const uint32_t k = kb + j;
+                ra[j] = (qok && k < d) ? qp[k] : 0.0f;
+                rb[j] = (xok && k < d) ? xp[k] : 0.0f;
+            }
+        }
+    };
+    fetch(0);
     for (uint32_t k0 = 0; k0 < d; k0 += kBK) {
 #pragma unroll
         for (int j = 0; j < 16; j++) {
-            const uint32_t k = k0 + 16 * kh + j;
-            As[(16 * kh + j) * kLd + sr] = (qok && k < d) ? qp[k] : 0.0f;
-            Bs[(16 * kh + j) * kLd + sr] = (xok && k < d) ? xp[k] : 0.0f;
+            As[(16 * kh + j) * kLd + sr] = ra[j];
+            Bs[(16 * kh + j) * kLd + sr] = rb[j];
         }
         __syncthreads();
+        if (k0 + kBK < d) fetch(k0 + kBK);
 #pragma unroll
         for (int kk = 0; kk < kBK; kk += 2) {
             float a[2], b[2];

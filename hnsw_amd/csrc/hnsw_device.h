@@ -29,7 +29,7 @@ struct DeviceGraph {
 
 // On-chip scratch configuration of one launch ("tier"): sizes of the per-query LDS structures.
 struct ScratchTier {
-    uint32_t hash_bits;   // visited set: 2^hash_bits slots of 4 bytes
+    uint32_t hash_size;   // visited set: slots of 4 bytes (a multiple of 64, any otherwise)
     uint32_t cap_c;       // candidate heap capacity (8-byte entries)
 };
 
@@ -39,7 +39,7 @@ struct SearchArgs {
     const uint32_t* qmap;     // optional: block -> query index (retry launches); nullptr = identity
     uint32_t nq_launch;       // blocks in this launch
     uint32_t ef, out_k, flags;
-    uint32_t hash_bits, cap_c, cap_w;   // cap_w: ef+1 rounded up to even
+    uint32_t hash_size, cap_c, cap_w;   // cap_w: ef+1 rounded up to even
     uint32_t qpad;            // floats of the query copy in LDS (multiple of 64)
     uint32_t* out_ids;        // nq x out_k
     float* out_dist;          // nq x out_k

@@ -255,14 +255,16 @@ __device__ __forceinline__ uint2 heap_pop_wave(uint2* a, uint32_t n /* size befo
 
 // Exact visited set: open addressing, linear probing, one LDS compare-and-swap per probe.
 // Returns true when `id` was not in the set (and now is).
-__device__ __forceinline__ bool visited_insert(uint32_t* hash, uint32_t mask, uint32_t shift, uint32_t id)
+// The table has `size` slots, any number (no power of two needed): the start slot is the
+// multiplicative hash scaled to the table, and the probe wraps by comparison.
+__device__ __forceinline__ bool visited_insert(uint32_t* hash, uint32_t size, uint32_t id)
 {
-    uint32_t slot = (id * 0x9E3779B1u) >> shift;
+    uint32_t slot = __umulhi(id * 0x9E3779B1u, size);
     for (;;) {
         uint32_t old = atomicCAS(&hash[slot], kEmpty, id);
         if (old == kEmpty) return true;
         if (old == id) return false;
-        slot = (slot + 1) & mask;
+        slot = slot + 1 == size ? 0u : slot + 1;
     }
 }
 
@@ -584,7 +586,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
     uint2* W = reinterpret_cast<uint2*>(smem + a.qpad);
     uint2* C = W + (WR == 0 ? a.cap_w : 0u);
     uint32_t* hash = reinterpret_cast<uint32_t*>(C + a.cap_c);
-    const uint32_t H = 1u << a.hash_bits, hmask = H - 1, hshift = 32 - a.hash_bits;
+    const uint32_t H = a.hash_size;
     const uint32_t visit_limit = H - (H >> 3);       // keep the table at most 7/8 full
     const DistCtx dc = make_dist_ctx<SCALAR>(qs, a.g.d);
     const bool float_keys = (a.flags & HNSW_AMD_KEYS_FLOAT) != 0;
@@ -614,7 +616,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
     const int L = (int)a.g.nlayers - 1;
     uint32_t cur_slot = a.g.top_ep_slot, cur_id = a.g.top_ep_order;
     float cur_dist;
-    if (lane == 0) visited_insert(hash, hmask, hshift, cur_id);
+    if (lane == 0) visited_insert(hash, H, cur_id);
     {
         uint32_t rid[RM::kSub]; bool act[RM::kSub]; float dj[RM::kSub];
 #pragma unroll
@@ -642,7 +644,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
                 uint32_t my_order = kEmpty, my_slot = kEmpty;           // merged form
                 if (b0 + mrow < a.g.degu) { my_order = a.g.up_adj_order[rowi + b0 + mrow]; my_slot = a.g.up_adj_slot[rowi + b0 + mrow]; }
                 const bool live = my_order != kEmpty;
-                const bool fresh = live && visited_insert(hash, hmask, hshift, my_order);
+                const bool fresh = live && visited_insert(hash, H, my_order);
                 const uint32_t m = (uint32_t)__popcll(__ballot(fresh));
                 st.sum_degu += (uint32_t)__popcll(__ballot(live));
                 st.n_dist += m; nvis += m;
@@ -683,7 +685,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
         if (lane == 0) {
             if (WR == 0) W[0] = make_uint2(__float_as_uint(cur_dist), cur_id);
             C[0] = make_uint2(float_keys ? __float_as_uint(cur_dist) : (uint32_t)trunc_key(cur_dist), cur_id);
-            visited_insert(hash, hmask, hshift, cur_id);
+            visited_insert(hash, H, cur_id);
         }
 #pragma unroll
         for (int w = 0; w < (WR > 0 ? WR : 1); w++) { wd[w] = 0; wi[w] = 0; }
@@ -716,7 +718,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
                 if (nvis + 64 > visit_limit) { fail = 1; break; }
                 const bool live = my != kEmpty;
                 const uint32_t nlive = (uint32_t)__popcll(__ballot(live));
-                const bool fresh = live && visited_insert(hash, hmask, hshift, my);
+                const bool fresh = live && visited_insert(hash, H, my);
                 const uint32_t m = (uint32_t)__popcll(__ballot(fresh));
                 st.sum_deg0 += nlive; st.n_dist += m; nvis += m;
                 LDS_SYNC();
@@ -965,7 +967,7 @@ __global__ void store_rows_q8_kernel(const float* __restrict__ src, uint8_t* __r
 
 size_t search_lds_bytes(const SearchArgs& a, bool w_in_lds)
 {
-    size_t dwords = (size_t)a.qpad + (w_in_lds ? 2 * (size_t)a.cap_w : 0) + 2 * (size_t)a.cap_c + ((size_t)1 << a.hash_bits);
+    size_t dwords = (size_t)a.qpad + (w_in_lds ? 2 * (size_t)a.cap_w : 0) + 2 * (size_t)a.cap_c + (size_t)a.hash_size;
     return dwords * 4;
 }
 
@@ -1101,13 +1103,13 @@ static ScratchTier tier_for(int ef, int tier)
     // Sized from measured search statistics (visited ~ 16-25 x ef on graphs of 10^4..10^6
     // nodes, candidate heap <= ~6 x ef on integer data); a query that outgrows a tier is
     // re-run on the next one.
-    uint32_t want_visit = (uint32_t)ef * 28u + 256u;
-    uint32_t bits = 10;
-    while ((1u << bits) - (1u << (bits - 3)) < want_visit + 64) bits++;
+    const uint32_t want_visit = (uint32_t)ef * 28u + 192u;
+    // at most 7/8 full, with room for one more neighbour list of 64
+    uint32_t hash_size = (((want_visit + 64u) * 8u + 6u) / 7u + 63u) & ~63u;
     uint32_t cap_c = ((uint32_t)ef * 4u + 63u) & ~63u;
-    bits += (uint32_t)tier;
+    hash_size <<= tier;
     cap_c <<= tier;
-    return ScratchTier{bits, cap_c};
+    return ScratchTier{hash_size, cap_c};
 }
 
 uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32_t out_k, uint32_t flags, uint32_t* d_ids,
@@ -1155,7 +1157,7 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
     int crowded_tier = first_tier;
     for (int tier = first_tier;; tier++) {
         ScratchTier t = tier_for(ef, tier);
-        a.hash_bits = t.hash_bits; a.cap_c = t.cap_c;
+        a.hash_size = t.hash_size; a.cap_c = t.cap_c;
         const bool std_heap = (flags & HNSW_AMD_W_STD_HEAP) != 0 || ef > 256;
         if (!std_heap && a.cap_w > a.cap_c) throw std::logic_error("search: W does not fit the space it borrows for the final sort");
         size_t lds = search_lds_bytes(a, std_heap);
@@ -1177,8 +1179,8 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
         if (getenv("HNSW_AMD_VERBOSE")) {
             int nb = 0;
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), 64, lds);
-            fprintf(stderr, "[hnsw_amd] search launch: %u queries, ef=%d, tier %d (hash 2^%u, C %u), LDS %zu B, resident queries per CU %d\n",
-                    a.nq_launch, ef, tier, a.hash_bits, a.cap_c, lds, nb);
+            fprintf(stderr, "[hnsw_amd] search launch: %u queries, ef=%d, tier %d (visited %u slots, C %u), LDS %zu B, resident queries per CU %d\n",
+                    a.nq_launch, ef, tier, a.hash_size, a.cap_c, lds, nb);
         }
         hipLaunchKernelGGL(kern, dim3(a.nq_launch), dim3(64), lds, stream, a);
         HIP_CHECK(hipGetLastError());
