@@ -285,22 +285,42 @@ void HostIndex::link(int layer, uint32_t new_slot, uint32_t id, const std::vecto
 {
     LayerStore& L = layers_[layer];
     const uint32_t cap = layer == 0 ? (uint32_t)Mmax0_ : (uint32_t)Mmax_;
-    // The new node's own list first: nothing points at the node yet, so no other thread can
-    // touch it (the reference appends to it inside the loop below, with the same outcome).
+    // The new node's own list first (the reference appends to it inside the loop below, with the
+    // same outcome).  In a concurrent build another insert can already have reached this slot through
+    // the node's link in the layer above and appended itself here: those entries are kept, behind the
+    // selected ones, unless the selection holds them as well.
     {
         SpinGuard g(MT ? &locks_[layer][new_slot] : nullptr);
         if (R.size() > L.deg) throw std::logic_error("link: selected more neighbours than a list holds");
-        for (size_t i = 0; i < R.size(); i++) {
-            size_t at = (size_t)new_slot * L.deg + i;
-            L.nb_slot[at] = R[i].slot; L.nb_order[at] = R[i].node_order; L.nb_dist[at] = R[i].distance;
+        const size_t base = (size_t)new_slot * L.deg;
+        std::vector<Neighbor>& early = s.Rov;
+        early.clear();
+        if (MT)
+            for (uint32_t j = 0; j < L.cnt[new_slot]; j++) early.push_back(Neighbor{L.nb_dist[base + j], L.nb_order[base + j], L.nb_slot[base + j]});
+        uint32_t k = 0;
+        for (size_t i = 0; i < R.size(); i++, k++) {
+            L.nb_slot[base + k] = R[i].slot; L.nb_order[base + k] = R[i].node_order; L.nb_dist[base + k] = R[i].distance;
         }
-        L.cnt[new_slot] = (uint32_t)R.size();
+        for (const Neighbor& x : early) {
+            bool dup = false;
+            for (size_t i = 0; i < R.size() && !dup; i++) dup = R[i].node_order == x.node_order;
+            if (dup || k >= cap) continue;
+            L.nb_slot[base + k] = x.slot; L.nb_order[base + k] = x.node_order; L.nb_dist[base + k] = x.distance; k++;
+        }
+        for (uint32_t j = k; j < L.deg; j++) { L.nb_slot[base + j] = kPad; L.nb_order[base + j] = kPad; L.nb_dist[base + j] = 0.0f; }
+        L.cnt[new_slot] = k;
     }
     for (size_t i = 0; i < R.size(); i++) {
         const Neighbor& e = R[i];
         SpinGuard g(MT ? &locks_[layer][e.slot] : nullptr);
         const size_t base = (size_t)e.slot * L.deg;
         uint32_t ecnt = L.cnt[e.slot];
+        if (MT) {
+            // that neighbour may have linked to this node on its own already (see above)
+            bool have = false;
+            for (uint32_t j = 0; j < ecnt && !have; j++) have = L.nb_order[base + j] == id;
+            if (have) continue;
+        }
         if (ecnt == cap) {
             s.Wov.resize(ecnt);
             for (uint32_t j = 0; j < ecnt; j++) s.Wov[j] = Neighbor{L.nb_dist[base + j], L.nb_order[base + j], L.nb_slot[base + j]};

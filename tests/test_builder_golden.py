@@ -69,3 +69,31 @@ def test_concurrent_build_is_a_valid_graph_of_the_same_shape():
     # comparable connectivity
     assert abs(float(fa.cnt0.mean()) - float(fb.cnt0.mean())) < 2.0
     assert int(fb.cnt0.min()) >= 1
+
+
+def test_concurrent_build_keeps_every_list_well_formed():
+    """Many threads, long lists, few nodes: inserts overlap as much as they can.  Every exported list must be a
+    prefix of distinct in-range ids followed by padding (export_flat validates the padding), every node
+    reachable from layer 0's lists must exist, and the graph must be searchable (recall by the CPU checker)."""
+    import numpy as np
+    from hnsw_amd import HNSW, datagen
+    from oracle import oracle
+    from tests.helpers import recall_at_k
+    n = 6000
+    base = datagen.make("deep", n, seed=11)
+    q = datagen.make("deep", 50, seed=11, stream=1)
+    gt = oracle.bruteforce(base, q, 10, threads=4)
+    for rep in range(25):
+        h = HNSW(32, 32, 60)
+        h.init(96, n)
+        h.insert_batch(base, threads=16)
+        fg = h.export_flat()            # validates ranges and padding
+        for adj, cnt in ((fg.adj0, fg.cnt0), (fg.up_adj_order, fg.up_cnt)):
+            if adj.size == 0:
+                continue
+            srt = np.sort(adj.astype(np.int64), axis=1)
+            dup = (srt[:, 1:] == srt[:, :-1]) & (srt[:, 1:] != 0xFFFFFFFF)
+            assert not dup.any(), f"rep {rep}: a neighbour list holds an id twice"
+        if rep % 8 == 0:
+            ids, _, _ = oracle.OracleIndex(fg, base).search(q, 64, out_k=10, key_mode=oracle.KEYS_FLOAT, threads=4)
+            assert recall_at_k(ids, gt, 10) > 0.9
