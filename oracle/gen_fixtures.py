@@ -38,6 +38,7 @@ CASES = {
     "unit_d96_n3000": dict(kind="deep", d=96, n=3000, nq=100, ctor=(16, 16, 200), build="sse", efs=[20, 100]),
     "int_d16_n1000_m5": dict(kind="sift", d=16, n=1000, nq=100, ctor=(5, 5, 20), build="sse", efs=[3, 10, 40],
                              savegraph=True),
+    "int_d32_n1500_m32": dict(kind="sift", d=32, n=1500, nq=100, ctor=(32, 32, 60), build="sse", efs=[10, 64]),   # lists of 64 / 32
     "gistlike_d960_n600": dict(kind="gist", d=960, n=600, nq=40, ctor=(16, 16, 200), build="sse", efs=[10, 64]),
 }
 # adjacency hashes only (pins the restated builder at a larger size)

@@ -10,7 +10,7 @@ from tests.helpers import Golden, assert_same_results
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name", ["int_d32_n2000", "int_d128_n4000", "int_d16_n1000_m5"])
+@pytest.mark.parametrize("name", ["int_d32_n2000", "int_d128_n4000", "int_d16_n1000_m5", "int_d32_n1500_m32"])
 def test_byte_rows_reproduce_the_reference_W(name):
     g = Golden(name)
     h = HNSW(*g.meta["ctor"])
