@@ -1182,8 +1182,19 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
             fprintf(stderr, "[hnsw_amd] search launch: %u queries, ef=%d, tier %d (visited %u slots, C %u), LDS %zu B, resident queries per CU %d\n",
                     a.nq_launch, ef, tier, a.hash_size, a.cap_c, lds, nb);
         }
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        const bool timed = getenv("HNSW_AMD_VERBOSE") != nullptr && sync_and_retry;
+        if (timed) { HIP_CHECK(hipEventCreate(&ev0)); HIP_CHECK(hipEventCreate(&ev1)); HIP_CHECK(hipEventRecord(ev0, stream)); }
         hipLaunchKernelGGL(kern, dim3(a.nq_launch), dim3(64), lds, stream, a);
         HIP_CHECK(hipGetLastError());
+        if (timed) {
+            HIP_CHECK(hipEventRecord(ev1, stream));
+            HIP_CHECK(hipEventSynchronize(ev1));
+            float ms = 0.0f;
+            HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1));
+            fprintf(stderr, "[hnsw_amd] search kernel: %.4f ms for %u queries\n", ms, a.nq_launch);
+            (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
+        }
         if (!sync_and_retry) return 0;
         HIP_CHECK(hipMemcpyAsync(h_fail, cur, 4, hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
