@@ -162,20 +162,8 @@ struct COrder {   // comp(a,b) = a.key > b.key
     static __device__ __forceinline__ bool before(uint2 a, uint2 b) { return (int32_t)a.x > (int32_t)b.x; }
 };
 
-// Maximum of an unsigned value over the 64 lanes with DPP moves (no LDS round trips):
+// Minimum of an unsigned value over the 64 lanes with DPP moves (no LDS round trips):
 // within quads, half rows and rows, then across the four rows; the result is read from lane 63.
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t x)
-{
-    uint32_t y;
-    y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0xB1, 0xF, 0xF, false); x = x > y ? x : y;    // quad_perm [1,0,3,2]
-    y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x4E, 0xF, 0xF, false); x = x > y ? x : y;    // quad_perm [2,3,0,1]
-    y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x141, 0xF, 0xF, false); x = x > y ? x : y;   // row_half_mirror
-    y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x140, 0xF, 0xF, false); x = x > y ? x : y;   // row_mirror
-    y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x142, 0xA, 0xF, false); x = x > y ? x : y;   // row_bcast15 -> rows 1,3
-    y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x143, 0xC, 0xF, false); x = x > y ? x : y;   // row_bcast31 -> rows 2,3
-    return __builtin_amdgcn_readlane(x, 63);
-}
-
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t x)
 {
     uint32_t y;
@@ -557,10 +545,49 @@ struct BatchLanes {
     }
 };
 
+// The result list W in registers: entry e lives in register e / 64, lane e % 64, and the nW valid
+// entries are kept ascending by distance.  Insert = count the entries not larger than the new one
+// (one ballot per register), move the rest up by one (a wave-wide DPP shift, lane 63 carried into
+// the next register) and drop the new entry into the gap; with W full the largest entry falls
+// off the end.  Non-negative floats order as their bit patterns.
+template <int WR>
+__device__ __forceinline__ void w_sorted_insert(uint32_t (&wd)[WR], uint32_t (&wi)[WR], uint32_t nW, uint32_t db, uint32_t id, int lane)
+{
+    uint32_t pos = 0;
+#pragma unroll
+    for (int w = 0; w < WR; w++) {
+        const uint32_t left = nW > 64u * w ? nW - 64u * w : 0u;
+        const unsigned long long valid = left >= 64u ? ~0ull : (1ull << left) - 1ull;
+        pos += (uint32_t)__popcll(__ballot(wd[w] <= db) & valid);
+    }
+#pragma unroll
+    for (int w = WR - 1; w >= 0; w--) {
+        uint32_t sd = (uint32_t)__builtin_amdgcn_update_dpp((int)wd[w], (int)wd[w], 0x138, 0xF, 0xF, false);   // wave_shr:1
+        uint32_t si = (uint32_t)__builtin_amdgcn_update_dpp((int)wi[w], (int)wi[w], 0x138, 0xF, 0xF, false);
+        if (w > 0) {
+            const uint32_t cd = __builtin_amdgcn_readlane(wd[w - 1], 63), ci = __builtin_amdgcn_readlane(wi[w - 1], 63);
+            if (lane == 0) { sd = cd; si = ci; }
+        }
+        const uint32_t e = 64u * w + (uint32_t)lane;
+        if (e > pos) { wd[w] = sd; wi[w] = si; }
+        if (e == pos) { wd[w] = db; wi[w] = id; }
+    }
+}
+
+template <int WR>
+__device__ __forceinline__ uint32_t w_entry_dist(const uint32_t (&wd)[WR], uint32_t e)
+{
+    uint32_t v = 0;
+#pragma unroll
+    for (int w = 0; w < WR; w++)
+        if ((e >> 6) == (uint32_t)w) v = __builtin_amdgcn_readlane(wd[w], e & 63u);
+    return v;
+}
+
 // WR = 0: the result list W is the libstdc++ max-heap in LDS, maintained exactly as the
 //         reference does (so even the choice among several equally distant worst entries
 //         is the reference's).
-// WR > 0: W is an unordered set, WR entries per lane in registers (ef <= 64*WR).  Only the
+// WR > 0: W is a sorted list, WR entries per lane in registers (ef <= 64*WR).  Only the
 //         largest distance f and the size of W steer the search, and both evolve
 //         identically; the one observable difference is which of several entries with
 //         exactly the worst distance is dropped.
@@ -591,7 +618,6 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
     const DistCtx dc = make_dist_ctx<SCALAR>(qs, a.g.d);
     const bool float_keys = (a.flags & HNSW_AMD_KEYS_FLOAT) != 0;
     const uint32_t ef = a.ef;
-    const unsigned long long w_valid = ef < 64 ? (1ull << ef) - 1ull : ~0ull;     // lanes of a full one-entry-per-lane W
 
     // query into LDS in stored form (zero padded), visited set empty
     {
@@ -738,8 +764,8 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
                     unsigned long long todo = __ballot(fresh && (dm < f || nW < ef));
                     if (nC + (uint32_t)__popcll(todo) > a.cap_c) { fail = 2; break; }
                     const uint32_t keym = float_keys ? __float_as_uint(dm) : (uint32_t)trunc_key(dm);
-                    if (WR == 1 && nW == ef) {
-                        // W is full (the usual state): its size and the lane of its largest entry are fixed
+                    if (WR > 0 && nW == ef) {
+                        // W is full (the usual state): its size and the place of its largest entry are fixed
                         while (todo) {
                             const int j = __builtin_ctzll(todo);
                             todo &= todo - 1;
@@ -750,12 +776,8 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
                                 nC++;
                                 if (nC <= kWaveHeapMax) heap_push_wave<COrder>(C, nC, ce, lane);
                                 else { if (lane == 0) { C[nC - 1] = ce; c_push(C, nC); } }
-                                const uint32_t pos = (uint32_t)__popcll(__ballot(wd[0] <= db) & w_valid);
-                                const uint32_t sd = (uint32_t)__builtin_amdgcn_update_dpp((int)wd[0], (int)wd[0], 0x138, 0xF, 0xF, false);   // wave_shr:1
-                                const uint32_t si = (uint32_t)__builtin_amdgcn_update_dpp((int)wi[0], (int)wi[0], 0x138, 0xF, 0xF, false);
-                                if ((uint32_t)lane > pos) { wd[0] = sd; wi[0] = si; }
-                                if ((uint32_t)lane == pos) { wd[0] = db; wi[0] = id; }
-                                f = __uint_as_float(__builtin_amdgcn_readlane(wd[0], ef - 1));
+                                w_sorted_insert<(WR > 0 ? WR : 1)>(wd, wi, ef, db, id, lane);
+                                f = __uint_as_float(w_entry_dist<(WR > 0 ? WR : 1)>(wd, ef - 1));
                                 LDS_SYNC();
                             }
                         }
@@ -773,38 +795,9 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
                             if (WR > 0) {
                                 if (nC <= kWaveHeapMax) heap_push_wave<COrder>(C, nC, ce, lane);
                                 else { if (lane == 0) { C[nC - 1] = ce; c_push(C, nC); } }
-                                if (WR == 1) {
-                                    // one entry per lane, kept ascending over lanes 0..nW-1: the new entry goes behind
-                                    // the entries not larger than it, the rest move up one lane, and with W full
-                                    // the largest one falls off the end
-                                    const unsigned long long valid = nW < 64 ? (1ull << nW) - 1ull : ~0ull;
-                                    const uint32_t pos = (uint32_t)__popcll(__ballot(wd[0] <= we.x) & valid);
-                                    const uint32_t sd = (uint32_t)__builtin_amdgcn_update_dpp((int)wd[0], (int)wd[0], 0x138, 0xF, 0xF, false);   // wave_shr:1
-                                    const uint32_t si = (uint32_t)__builtin_amdgcn_update_dpp((int)wi[0], (int)wi[0], 0x138, 0xF, 0xF, false);
-                                    if ((uint32_t)lane > pos) { wd[0] = sd; wi[0] = si; }
-                                    if ((uint32_t)lane == pos) { wd[0] = we.x; wi[0] = we.y; }
-                                    if (nW < ef) nW++;
-                                    f = __uint_as_float(__builtin_amdgcn_readlane(wd[0], nW - 1));
-                                } else if (nW < ef) {
-                                    // W not full: append; f stays the largest distance in W
-#pragma unroll
-                                    for (int w = 0; w < WR; w++)
-                                        if ((nW >> 6) == (uint32_t)w && (nW & 63u) == (uint32_t)lane) { wd[w] = we.x; wi[w] = we.y; }
-                                    nW++;
-                                    f = dist > f ? dist : f;
-                                } else {
-                                    // W full and dist < f: the new entry replaces one entry at distance f
-                                    const uint32_t fb = __float_as_uint(f);
-                                    bool done = false;
-                                    uint32_t mx = 0;
-#pragma unroll
-                                    for (int w = 0; w < WR; w++) {
-                                        const unsigned long long hit = done ? 0ull : __ballot(wd[w] == fb);
-                                        if (hit) { if (lane == __builtin_ctzll(hit)) { wd[w] = we.x; wi[w] = we.y; } done = true; }
-                                        mx = wd[w] > mx ? wd[w] : mx;
-                                    }
-                                    f = __uint_as_float(wave_max_u32(mx));   // non-negative floats order as their bit patterns
-                                }
+                                w_sorted_insert<(WR > 0 ? WR : 1)>(wd, wi, nW, we.x, we.y, lane);
+                                if (nW < ef) nW++;
+                                f = __uint_as_float(w_entry_dist<(WR > 0 ? WR : 1)>(wd, nW - 1));
                                 LDS_SYNC();
                             } else {
                                 nW++;
