@@ -410,9 +410,10 @@ __device__ __forceinline__ void consume_item_scalar(const float* qp, uint32_t e0
 
 // Distances from the query to up to kSub rows per lane group: row[s] points at the stored row
 // (already offset to this lane's part), act[s] says whether the lane takes part.  out[s] is
-// valid in every lane of the row's group.  Called by all 64 lanes.  The loads of two items are
-// in flight at any time; with rows of up to 128 dims that is both sub-batches of an SSE batch.
-template <bool SCALAR>
+// valid in every lane of the row's group.  Called by all 64 lanes.  The loads of NBUF = 2 items are
+// in flight at any time; with rows of up to 128 dims that is both sub-batches of an SSE batch.  (Four
+// items in flight were measured on 960-dim rows: more registers, no gain.)
+template <bool SCALAR, int NBUF>
 __device__ __forceinline__ void batch_distance(const DistCtx& c, const float* const (&row)[RowMap<SCALAR>::kSub],
                                                const bool (&act)[RowMap<SCALAR>::kSub], float (&out)[RowMap<SCALAR>::kSub], int lane)
 {
@@ -422,16 +423,16 @@ __device__ __forceinline__ void batch_distance(const DistCtx& c, const float* co
     float acc[RM::kSub];
 #pragma unroll
     for (int s = 0; s < RM::kSub; s++) acc[s] = 0.0f;
-    float4 A[8], B[8];
-    // item i of the sequence: sub-batch i / ni, item i % ni of its rows
+    float4 buf[NBUF][8];
+    // item i of the sequence: the sub-batches take turns, item i / kSub of sub-batch i % kSub
     const uint32_t total = RM::kSub * ni;
     auto issue = [&](float4 (&v)[8], uint32_t i) {
-        const uint32_t s = SCALAR ? 0u : (i >= ni ? 1u : 0u), g = i - s * ni;
+        const uint32_t s = SCALAR ? 0u : (i & 1u), g = SCALAR ? i : (i >> 1);
         const float* p = (s ? row[RM::kSub - 1] : row[0]) + g * RM::kItemFloats;
         if (s ? act[RM::kSub - 1] : act[0]) { if (g < nf) issue_item<SCALAR, true>(p, 0, v); else issue_item<SCALAR, false>(p, tl, v); }
     };
     auto consume = [&](const float4 (&v)[8], uint32_t i) {
-        const uint32_t s = SCALAR ? 0u : (i >= ni ? 1u : 0u), g = i - s * ni;
+        const uint32_t s = SCALAR ? 0u : (i & 1u), g = SCALAR ? i : (i >> 1);
         const float* qp = qs + g * RM::kItemFloats;
         float a = s ? acc[RM::kSub - 1] : acc[0];
         if (s ? act[RM::kSub - 1] : act[0]) {
@@ -440,15 +441,16 @@ __device__ __forceinline__ void batch_distance(const DistCtx& c, const float* co
         }
         if (s) acc[RM::kSub - 1] = a; else acc[0] = a;
     };
-    issue(A, 0);
-    if (total > 1) issue(B, 1);
-    for (uint32_t i = 0; i < total; i += 2) {
-        consume(A, i);
-        if (i + 2 < total) issue(A, i + 2);
-        if (i + 1 < total) {
-            consume(B, i + 1);
-            if (i + 3 < total) issue(B, i + 3);
-        }
+#pragma unroll
+    for (int b = 0; b < NBUF; b++)
+        if ((uint32_t)b < total) issue(buf[b], b);
+    for (uint32_t i = 0; i < total; i += NBUF) {
+#pragma unroll
+        for (int b = 0; b < NBUF; b++)
+            if (i + b < total) {
+                consume(buf[b], i + b);
+                if (i + b + NBUF < total) issue(buf[b], i + b + NBUF);
+            }
     }
 #pragma unroll
     for (int s = 0; s < RM::kSub; s++) {
@@ -502,7 +504,7 @@ __device__ __forceinline__ void batch_distance_u8(const DistCtx& c, const uint8_
 }
 
 // Distances to the rows `id[s]` (sub-batch s; act[s]: the lane's row takes part), from the float or the byte table.
-template <bool SCALAR, int ROWS>
+template <bool SCALAR, int ROWS, int NBUF = 2>
 __device__ __forceinline__ void rows_distance(const DeviceGraph& g, const DistCtx& c, const uint32_t (&id)[RowMap<SCALAR>::kSub],
                                               const bool (&act)[RowMap<SCALAR>::kSub], float (&out)[RowMap<SCALAR>::kSub], int lane)
 {
@@ -518,7 +520,7 @@ __device__ __forceinline__ void rows_distance(const DeviceGraph& g, const DistCt
         const float* row[RM::kSub];
 #pragma unroll
         for (int s = 0; s < RM::kSub; s++) row[s] = g.vectors + (size_t)id[s] * g.row_stride + (SCALAR ? 0u : 8u * (lane & 3));
-        batch_distance<SCALAR>(c, row, act, out, lane);
+        batch_distance<SCALAR, NBUF>(c, row, act, out, lane);
     }
 }
 
@@ -599,6 +601,7 @@ __device__ __forceinline__ uint32_t w_entry_dist(const uint32_t (&wd)[WR], uint3
 template <bool SCALAR, int WR, int ROWS>
 __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
 {
+    constexpr int NBUF = 2;
     typedef RowMap<SCALAR> RM;
     typedef BatchLanes<SCALAR> BL;
     extern __shared__ __align__(16) uint32_t smem[];
@@ -647,7 +650,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
         uint32_t rid[RM::kSub]; bool act[RM::kSub]; float dj[RM::kSub];
 #pragma unroll
         for (int s = 0; s < RM::kSub; s++) { rid[s] = cur_id; act[s] = s == 0 && lane < RM::kLanesPerRow; }
-        rows_distance<SCALAR, ROWS>(a.g, dc, rid, act, dj, lane);
+        rows_distance<SCALAR, ROWS, NBUF>(a.g, dc, rid, act, dj, lane);
         cur_dist = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(dj[0]), 0));
     }
     st.n_dist = 1;
@@ -679,7 +682,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
                 uint32_t rid[RM::kSub]; bool act[RM::kSub]; float dj[RM::kSub];
 #pragma unroll
                 for (int s = 0; s < RM::kSub; s++) { rid[s] = BL::spread(my_order, s); act[s] = BL::spread((uint32_t)fresh, s) != 0; }
-                rows_distance<SCALAR, ROWS>(a.g, dc, rid, act, dj, lane);
+                rows_distance<SCALAR, ROWS, NBUF>(a.g, dc, rid, act, dj, lane);
                 const float dm = (!SCALAR && (lane & 3) == 1) ? dj[RM::kSub - 1] : dj[0];      // merged form
                 const bool mine = fresh && dm == dm;
                 const uint32_t key = mine ? __float_as_uint(dm) : 0x7F800000u;     // non-negative floats order as their bit patterns
@@ -754,7 +757,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
                     uint32_t rid[RM::kSub]; bool act[RM::kSub]; float dj[RM::kSub];
 #pragma unroll
                     for (int s = 0; s < RM::kSub; s++) { rid[s] = BL::spread(my, s); act[s] = BL::spread((uint32_t)fresh, s) != 0; }
-                    rows_distance<SCALAR, ROWS>(a.g, dc, rid, act, dj, lane);
+                    rows_distance<SCALAR, ROWS, NBUF>(a.g, dc, rid, act, dj, lane);
                     const float dm = (!SCALAR && (lane & 3) == 1) ? dj[RM::kSub - 1] : dj[0];      // merged form
                     DIAG_STAMP(t3);
                     DIAG_ADD(cy_dist, t2, t3);
@@ -1048,6 +1051,7 @@ void DeviceIndex::upload(const HostIndex& h, int dev)
     HIP_CHECK(hipDeviceSynchronize());
     version = h.version_;
     hint_tier = 0; hint_ef = 0; hint_flags = 0;
+    scratch_scale = 1.0f; scale_flags = 0;
 }
 
 void DeviceIndex::ensure_quantized(const HostIndex& h)
@@ -1091,15 +1095,36 @@ void DeviceIndex::ensure_quantized(const HostIndex& h)
     g.vectors_q8 = dq;
 }
 
-static ScratchTier tier_for(int ef, int tier)
+typedef void (*SearchKernel)(SearchArgs);
+
+template <bool SCALAR, int ROWS>
+static SearchKernel pick_wr(int wr)
+{
+    switch (wr) {
+        case 0: return hnsw_search_kernel<SCALAR, 0, ROWS>;
+        case 1: return hnsw_search_kernel<SCALAR, 1, ROWS>;
+        case 2: return hnsw_search_kernel<SCALAR, 2, ROWS>;
+        default: return hnsw_search_kernel<SCALAR, 4, ROWS>;
+    }
+}
+
+static SearchKernel pick_kernel(bool scalar, int wr, int rows)
+{
+    if (scalar) return pick_wr<true, 0>(wr);
+    if (rows == 1) return pick_wr<false, 1>(wr);
+    if (rows == 2) return pick_wr<false, 2>(wr);
+    return pick_wr<false, 0>(wr);
+}
+
+static ScratchTier tier_for(int ef, int tier, float scale)
 {
     // Sized from measured search statistics (visited ~ 16-25 x ef on graphs of 10^4..10^6
     // nodes, candidate heap <= ~6 x ef on integer data); a query that outgrows a tier is
     // re-run on the next one.
-    const uint32_t want_visit = (uint32_t)ef * 28u + 192u;
+    const uint32_t want_visit = (uint32_t)((float)((uint32_t)ef * 28u + 192u) * scale);
     // at most 7/8 full, with room for one more neighbour list of 64
     uint32_t hash_size = (((want_visit + 64u) * 8u + 6u) / 7u + 63u) & ~63u;
-    uint32_t cap_c = ((uint32_t)ef * 4u + 63u) & ~63u;
+    uint32_t cap_c = ((uint32_t)((float)((uint32_t)ef * 4u) * scale) + 63u) & ~63u;
     hash_size <<= tier;
     cap_c <<= tier;
     return ScratchTier{hash_size, cap_c};
@@ -1148,8 +1173,10 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
     // reference's int32 keys), running every query twice would double the work.
     const int first_tier = (hint_tier > 0 && 4 * ef >= 3 * hint_ef && flags == hint_flags) ? hint_tier : 0;
     int crowded_tier = first_tier;
+    bool grow_scale = false;
+    if (flags != scale_flags) { scratch_scale = 1.0f; scale_flags = flags; }
     for (int tier = first_tier;; tier++) {
-        ScratchTier t = tier_for(ef, tier);
+        ScratchTier t = tier_for(ef, tier, scratch_scale);
         a.hash_size = t.hash_size; a.cap_c = t.cap_c;
         const bool std_heap = (flags & HNSW_AMD_W_STD_HEAP) != 0 || ef > 256;
         if (!std_heap && a.cap_w > a.cap_c) throw std::logic_error("search: W does not fit the space it borrows for the final sort");
@@ -1162,10 +1189,7 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
         HIP_CHECK(hipMemsetAsync(cur, 0, 4, stream));
         void (*kern)(SearchArgs);
         const int wr = std_heap ? 0 : (ef <= 64 ? 1 : (ef <= 128 ? 2 : 4));
-        if (scalar) kern = wr == 0 ? hnsw_search_kernel<true, 0, 0> : (wr == 1 ? hnsw_search_kernel<true, 1, 0> : (wr == 2 ? hnsw_search_kernel<true, 2, 0> : hnsw_search_kernel<true, 4, 0>));
-        else if (u8) kern = wr == 0 ? hnsw_search_kernel<false, 0, 1> : (wr == 1 ? hnsw_search_kernel<false, 1, 1> : (wr == 2 ? hnsw_search_kernel<false, 2, 1> : hnsw_search_kernel<false, 4, 1>));
-        else if (q8) kern = wr == 0 ? hnsw_search_kernel<false, 0, 2> : (wr == 1 ? hnsw_search_kernel<false, 1, 2> : (wr == 2 ? hnsw_search_kernel<false, 2, 2> : hnsw_search_kernel<false, 4, 2>));
-        else kern = wr == 0 ? hnsw_search_kernel<false, 0, 0> : (wr == 1 ? hnsw_search_kernel<false, 1, 0> : (wr == 2 ? hnsw_search_kernel<false, 2, 0> : hnsw_search_kernel<false, 4, 0>));
+        kern = pick_kernel(scalar, wr, u8 ? 1 : (q8 ? 2 : 0));
         if (lds > 32768)
             HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         if (const char* pad = getenv("HNSW_AMD_LDS_PAD")) lds += (size_t)atoi(pad);      // occupancy experiments
@@ -1193,12 +1217,16 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
         HIP_CHECK(hipStreamSynchronize(stream));
         uint32_t nfail = h_fail[0];
         if (8 * (size_t)nfail >= nq) crowded_tier = tier + 1;      // an eighth of the batch or more needs the next tier
+        else if (nfail > 0 && tier == first_tier) grow_scale = true;   // a few stragglers: a slightly larger first tier next time
         if (nfail == 0) break;
         retried += nfail;
         a.qmap = cur + 1; a.nq_launch = nfail;
         std::swap(cur, other);
     }
     if (crowded_tier != first_tier || first_tier == 0) { hint_tier = crowded_tier; hint_ef = ef; hint_flags = flags; }
+    // A re-run of a handful of queries costs a whole query latency, so the tables of the first tier grow
+    // by a quarter whenever that happened, until batches of this kind no longer overflow.
+    if (grow_scale && scratch_scale < 8.0f) scratch_scale *= 1.25f;
     return retried;
 }
 
