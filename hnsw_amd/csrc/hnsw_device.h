@@ -31,6 +31,7 @@ struct DeviceGraph {
 struct ScratchTier {
     uint32_t hash_size;   // visited set: slots of 4 bytes (a multiple of 64, any otherwise)
     uint32_t cap_c;       // candidate heap capacity (8-byte entries)
+    uint32_t want_visit;  // visited ids the table is meant to hold
 };
 
 struct SearchArgs {
@@ -39,7 +40,8 @@ struct SearchArgs {
     const uint32_t* qmap;     // optional: block -> query index (retry launches); nullptr = identity
     uint32_t nq_launch;       // blocks in this launch
     uint32_t ef, out_k, flags;
-    uint32_t hash_size, cap_c, cap_w;   // cap_w: ef+1 rounded up to even
+    uint32_t hash_size, cap_c, cap_w;
+    uint32_t vis_rb;          // 0xFFFFFFFF: visited slots of 32 bits; else 16-bit slots in 2^vis_rb regions   // cap_w: ef+1 rounded up to even
     uint32_t qpad;            // floats of the query copy in LDS (multiple of 64)
     uint32_t* out_ids;        // nq x out_k
     float* out_dist;          // nq x out_k

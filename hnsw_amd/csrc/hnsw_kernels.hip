@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <stdexcept>
@@ -245,7 +246,7 @@ __device__ __forceinline__ uint2 heap_pop_wave(uint2* a, uint32_t n /* size befo
 // Returns true when `id` was not in the set (and now is).
 // The table has `size` slots, any number (no power of two needed): the start slot is the
 // multiplicative hash scaled to the table, and the probe wraps by comparison.
-__device__ __forceinline__ bool visited_insert(uint32_t* hash, uint32_t size, uint32_t id)
+__device__ __forceinline__ bool visited_insert32(uint32_t* hash, uint32_t size, uint32_t id)
 {
     uint32_t slot = __umulhi(id * 0x9E3779B1u, size);
     for (;;) {
@@ -254,6 +255,41 @@ __device__ __forceinline__ bool visited_insert(uint32_t* hash, uint32_t size, ui
         if (old == id) return false;
         slot = slot + 1 == size ? 0u : slot + 1;
     }
+}
+
+// Half-size form of the same exact set for large ef, where LDS decides how many queries a CU holds:
+// 2^rb regions selected by the low rb bits of the id, 16-bit slots holding the remaining bits
+// (the host checks that they fit below 0xFFFF = empty), linear probing inside the region.  A 16-bit
+// slot is claimed with a compare-and-swap on the 32-bit word around it.  A region can fill up
+// while the table as a whole has room: that is reported through `overflow` (the query is then
+// re-run with larger tables, like any other scratch overflow).
+__device__ __forceinline__ bool visited_insert16(uint32_t* hash, uint32_t rb, uint32_t per_region, uint32_t id, bool& overflow)
+{
+    const uint32_t tag = id >> rb;
+    const uint32_t first = (id & ((1u << rb) - 1u)) * per_region;
+    uint32_t slot = first + __umulhi(tag * 0x9E3779B1u, per_region);
+    for (uint32_t probes = 0; probes < per_region;) {
+        const uint32_t sh = (slot & 1u) * 16u;
+        const uint32_t old = *reinterpret_cast<volatile uint32_t*>(&hash[slot >> 1]);
+        const uint32_t half = (old >> sh) & 0xFFFFu;
+        if (half == tag) return false;
+        if (half == 0xFFFFu) {
+            const uint32_t want = (old & ~(0xFFFFu << sh)) | (tag << sh);
+            if (atomicCAS(&hash[slot >> 1], old, want) == old) return true;
+            continue;                                   // the word changed under us: look at the slot again
+        }
+        slot = slot + 1 == first + per_region ? first : slot + 1;
+        probes++;
+    }
+    overflow = true;
+    return false;
+}
+
+// vis_rb == 0xFFFFFFFF: 32-bit slots; otherwise the region form with that many region bits.
+__device__ __forceinline__ bool visited_insert(uint32_t* hash, uint32_t size, uint32_t vis_rb, uint32_t id, bool& overflow)
+{
+    if (vis_rb == 0xFFFFFFFFu) return visited_insert32(hash, size, id);
+    return visited_insert16(hash, vis_rb, size >> vis_rb, id, overflow);
 }
 
 // Diagnostic build only (-DHNSW_DIAG): the counters struct is overwritten with cycle sums
@@ -616,8 +652,10 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
     uint2* W = reinterpret_cast<uint2*>(smem + a.qpad);
     uint2* C = W + (WR == 0 ? a.cap_w : 0u);
     uint32_t* hash = reinterpret_cast<uint32_t*>(C + a.cap_c);
-    const uint32_t H = a.hash_size;
+    const uint32_t H = a.hash_size, vis_rb = a.vis_rb;
+    const uint32_t hash_words = vis_rb == 0xFFFFFFFFu ? H : H >> 1;
     const uint32_t visit_limit = H - (H >> 3);       // keep the table at most 7/8 full
+    bool vis_ovf = false;
     const DistCtx dc = make_dist_ctx<SCALAR>(qs, a.g.d);
     const bool float_keys = (a.flags & HNSW_AMD_KEYS_FLOAT) != 0;
     const uint32_t ef = a.ef;
@@ -630,7 +668,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
             if (ROWS == 2 && i < a.g.d) v = (v - a.g.q8_lo) * a.g.q8_inv_step;
             qs[ROWS != 0 ? stored_pos_u8(i) : stored_pos(i)] = v;
         }
-        for (uint32_t i = lane; i < H; i += 64) hash[i] = kEmpty;
+        for (uint32_t i = lane; i < hash_words; i += 64) hash[i] = kEmpty;
     }
     LDS_SYNC();
 
@@ -645,7 +683,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
     const int L = (int)a.g.nlayers - 1;
     uint32_t cur_slot = a.g.top_ep_slot, cur_id = a.g.top_ep_order;
     float cur_dist;
-    if (lane == 0) visited_insert(hash, H, cur_id);
+    if (lane == 0) visited_insert(hash, H, vis_rb, cur_id, vis_ovf);
     {
         uint32_t rid[RM::kSub]; bool act[RM::kSub]; float dj[RM::kSub];
 #pragma unroll
@@ -662,7 +700,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
     for (int l = L; l > 0 && !fail; l--) {
         const uint32_t base = a.g.up_off[l];
         bool change = true;
-        while (change) {
+        while (change && !fail) {
             change = false;
             if (nvis + 64 > visit_limit) { fail = 1; break; }
             st.n_sweeps++;
@@ -673,7 +711,8 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
                 uint32_t my_order = kEmpty, my_slot = kEmpty;           // merged form
                 if (b0 + mrow < a.g.degu) { my_order = a.g.up_adj_order[rowi + b0 + mrow]; my_slot = a.g.up_adj_slot[rowi + b0 + mrow]; }
                 const bool live = my_order != kEmpty;
-                const bool fresh = live && visited_insert(hash, H, my_order);
+                const bool fresh = live && visited_insert(hash, H, vis_rb, my_order, vis_ovf);
+                if (__ballot(vis_ovf)) { fail = 1; break; }
                 const uint32_t m = (uint32_t)__popcll(__ballot(fresh));
                 st.sum_degu += (uint32_t)__popcll(__ballot(live));
                 st.n_dist += m; nvis += m;
@@ -709,12 +748,12 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
     uint32_t wd[WR > 0 ? WR : 1], wi[WR > 0 ? WR : 1];     // register form of W: distance bits, id
     if (!fail) {
         LDS_SYNC();
-        for (uint32_t i = lane; i < H; i += 64) hash[i] = kEmpty;
+        for (uint32_t i = lane; i < hash_words; i += 64) hash[i] = kEmpty;
         LDS_SYNC();
         if (lane == 0) {
             if (WR == 0) W[0] = make_uint2(__float_as_uint(cur_dist), cur_id);
             C[0] = make_uint2(float_keys ? __float_as_uint(cur_dist) : (uint32_t)trunc_key(cur_dist), cur_id);
-            visited_insert(hash, H, cur_id);
+            visited_insert(hash, H, vis_rb, cur_id, vis_ovf);
         }
 #pragma unroll
         for (int w = 0; w < (WR > 0 ? WR : 1); w++) { wd[w] = 0; wi[w] = 0; }
@@ -747,7 +786,8 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
                 if (nvis + 64 > visit_limit) { fail = 1; break; }
                 const bool live = my != kEmpty;
                 const uint32_t nlive = (uint32_t)__popcll(__ballot(live));
-                const bool fresh = live && visited_insert(hash, H, my);
+                const bool fresh = live && visited_insert(hash, H, vis_rb, my, vis_ovf);
+                if (__ballot(vis_ovf)) { fail = 1; break; }
                 const uint32_t m = (uint32_t)__popcll(__ballot(fresh));
                 st.sum_deg0 += nlive; st.n_dist += m; nvis += m;
                 LDS_SYNC();
@@ -963,7 +1003,7 @@ __global__ void store_rows_q8_kernel(const float* __restrict__ src, uint8_t* __r
 
 size_t search_lds_bytes(const SearchArgs& a, bool w_in_lds)
 {
-    size_t dwords = (size_t)a.qpad + (w_in_lds ? 2 * (size_t)a.cap_w : 0) + 2 * (size_t)a.cap_c + (size_t)a.hash_size;
+    size_t dwords = (size_t)a.qpad + (w_in_lds ? 2 * (size_t)a.cap_w : 0) + 2 * (size_t)a.cap_c + (a.vis_rb == 0xFFFFFFFFu ? (size_t)a.hash_size : (size_t)a.hash_size / 2);
     return dwords * 4;
 }
 
@@ -1127,7 +1167,23 @@ static ScratchTier tier_for(int ef, int tier, float scale)
     uint32_t cap_c = ((uint32_t)((float)((uint32_t)ef * 4u) * scale) + 63u) & ~63u;
     hash_size <<= tier;
     cap_c <<= tier;
-    return ScratchTier{hash_size, cap_c};
+    return ScratchTier{hash_size, cap_c, want_visit << tier};
+}
+
+// The half-size (16-bit slot) form of the visited table for `want_visit` ids below n, if the ids fit:
+// region bits and total slots (regions x an even number of slots each).  Regions are sized for their
+// expected share plus four standard deviations; a region that overflows anyway re-runs the query.
+static bool visited16_shape(uint32_t n, uint32_t want_visit, uint32_t& rb, uint32_t& slots)
+{
+    rb = 0;
+    while (rb < 12 && ((n - 1u) >> rb) >= 0xFFFFu) rb++;
+    if (((n - 1u) >> rb) >= 0xFFFFu) return false;
+    const float share = (float)(want_visit + 64u) / (float)(1u << rb);
+    uint32_t per = (uint32_t)((share + 4.0f * sqrtf(share)) * 8.0f / 7.0f) + 2u;
+    per = (per + 1u) & ~1u;
+    if (per < 96u) return false;             // too small for the law of large numbers to help
+    slots = per << rb;
+    return true;
 }
 
 uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32_t out_k, uint32_t flags, uint32_t* d_ids,
@@ -1177,10 +1233,22 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
     if (flags != scale_flags) { scratch_scale = 1.0f; scale_flags = flags; }
     for (int tier = first_tier;; tier++) {
         ScratchTier t = tier_for(ef, tier, scratch_scale);
-        a.hash_size = t.hash_size; a.cap_c = t.cap_c;
+        a.hash_size = t.hash_size; a.cap_c = t.cap_c; a.vis_rb = 0xFFFFFFFFu;
         const bool std_heap = (flags & HNSW_AMD_W_STD_HEAP) != 0 || ef > 256;
         if (!std_heap && a.cap_w > a.cap_c) throw std::logic_error("search: W does not fit the space it borrows for the final sort");
         size_t lds = search_lds_bytes(a, std_heap);
+        {
+            // 16-bit visited slots where they let a CU hold more queries (LDS is the limit for larger ef;
+            // 16 per CU is what the registers allow anyway)
+            uint32_t rb = 0, slots = 0;
+            if (!getenv("HNSW_AMD_VISITED32") && visited16_shape(g.n, t.want_visit, rb, slots)) {
+                SearchArgs b = a;
+                b.hash_size = slots; b.vis_rb = rb;
+                const size_t lds16 = search_lds_bytes(b, std_heap);
+                const size_t occ32 = std::min<size_t>(16, (size_t)163840 / lds), occ16 = std::min<size_t>(16, (size_t)163840 / lds16);
+                if (occ16 > occ32) { a = b; lds = lds16; }
+            }
+        }
         if (lds > (size_t)max_lds) {
             throw std::length_error("search: " + std::to_string(a.nq_launch) +
                                     " queries outgrew the largest on-chip scratch configuration (ef too large for LDS?)");
@@ -1196,8 +1264,8 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
         if (getenv("HNSW_AMD_VERBOSE")) {
             int nb = 0;
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), 64, lds);
-            fprintf(stderr, "[hnsw_amd] search launch: %u queries, ef=%d, tier %d (visited %u slots, C %u), LDS %zu B, resident queries per CU %d\n",
-                    a.nq_launch, ef, tier, a.hash_size, a.cap_c, lds, nb);
+            fprintf(stderr, "[hnsw_amd] search launch: %u queries, ef=%d, tier %d (visited %u slots%s, C %u), LDS %zu B, resident queries per CU %d\n",
+                    a.nq_launch, ef, tier, a.hash_size, a.vis_rb == 0xFFFFFFFFu ? "" : " of 16 bits", a.cap_c, lds, nb);
         }
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         const bool timed = getenv("HNSW_AMD_VERBOSE") != nullptr && sync_and_retry;

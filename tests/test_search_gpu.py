@@ -136,3 +136,23 @@ def test_index_can_grow_between_searches():
     oi, od, oc = idx.search(base[300:310], 20)
     assert_same_results(ids, dist, oi, od, what="after growth")
     assert (ids[:, 0] == np.arange(300, 310)).all() or (dist[:, 0] == 0).all()
+
+
+def test_both_forms_of_the_visited_set_give_the_same_search(monkeypatch):
+    """For larger ef the launcher switches the visited set to 16-bit slots in id-selected regions (half the
+    LDS); HNSW_AMD_VISITED32 keeps the 32-bit form.  Both are exact sets, so everything must be equal."""
+    from hnsw_amd import datagen
+    n = 70000                                   # more than 65535 ids: two regions
+    base = datagen.make("sift", n, seed=9)
+    q = datagen.make("sift", 300, seed=9, stream=1)
+    h = HNSW(16, 16, 100)
+    h.init(128, n)
+    h.insert_batch(base, threads=16)
+    for ef in (60, 100, 200, 256):
+        monkeypatch.delenv("HNSW_AMD_VISITED32", raising=False)
+        a = h.search_batch(q, ef, stats=True)
+        monkeypatch.setenv("HNSW_AMD_VISITED32", "1")
+        b = h.search_batch(q, ef, stats=True)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+        for f in a[3].dtype.names:
+            assert np.array_equal(a[3][f], b[3][f]), f
