@@ -249,12 +249,12 @@ __device__ __forceinline__ uint2 heap_pop_wave(uint2* a, uint32_t n /* size befo
 __device__ __forceinline__ bool visited_insert32(uint32_t* hash, uint32_t size, uint32_t id)
 {
     uint32_t slot = __umulhi(id * 0x9E3779B1u, size);
-    for (;;) {
-        uint32_t old = atomicCAS(&hash[slot], kEmpty, id);
-        if (old == kEmpty) return true;
-        if (old == id) return false;
+    uint32_t old;
+    do {                                    // one exit: the lanes' loop masks stay simple
+        old = atomicCAS(&hash[slot], kEmpty, id);
         slot = slot + 1 == size ? 0u : slot + 1;
-    }
+    } while (old != kEmpty && old != id);
+    return old == kEmpty;
 }
 
 // Half-size form of the same exact set for large ef, where LDS decides how many queries a CU holds:
@@ -268,21 +268,24 @@ __device__ __forceinline__ bool visited_insert16(uint32_t* hash, uint32_t rb, ui
     const uint32_t tag = id >> rb;
     const uint32_t first = (id & ((1u << rb) - 1u)) * per_region;
     uint32_t slot = first + __umulhi(tag * 0x9E3779B1u, per_region);
-    for (uint32_t probes = 0; probes < per_region;) {
+    uint32_t probes = 0;
+    bool fresh = false, done = false;
+    do {
         const uint32_t sh = (slot & 1u) * 16u;
-        const uint32_t old = *reinterpret_cast<volatile uint32_t*>(&hash[slot >> 1]);
+        const uint32_t old = __hip_atomic_load(&hash[slot >> 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         const uint32_t half = (old >> sh) & 0xFFFFu;
-        if (half == tag) return false;
-        if (half == 0xFFFFu) {
+        if (half == tag) {
+            done = true;
+        } else if (half == 0xFFFFu) {
             const uint32_t want = (old & ~(0xFFFFu << sh)) | (tag << sh);
-            if (atomicCAS(&hash[slot >> 1], old, want) == old) return true;
-            continue;                                   // the word changed under us: look at the slot again
+            if (atomicCAS(&hash[slot >> 1], old, want) == old) { fresh = true; done = true; }
+            // else: the word changed under us, look at the slot again
+        } else {
+            slot = slot + 1 == first + per_region ? first : slot + 1;
+            if (++probes >= per_region) { overflow = true; done = true; }
         }
-        slot = slot + 1 == first + per_region ? first : slot + 1;
-        probes++;
-    }
-    overflow = true;
-    return false;
+    } while (!done);
+    return fresh;
 }
 
 // vis_rb == 0xFFFFFFFF: 32-bit slots; otherwise the region form with that many region bits.
