@@ -184,12 +184,11 @@ __device__ __forceinline__ void heap_push_wave(uint2* a, uint32_t n /* size incl
 {
     const uint32_t depth = 31u - (uint32_t)__clz((int)n);        // levels above index n-1
     uint2 x = make_uint2(0, 0);
-    bool c = false;
-    if ((uint32_t)lane < depth) { x = a[(n >> (lane + 1)) - 1]; c = Ord::before(x, v); }
-    const unsigned long long m = __ballot(c);
+    if ((uint32_t)lane < depth) x = a[(n >> (lane + 1)) - 1];
+    const unsigned long long m = __ballot((uint32_t)lane < depth && Ord::before(x, v));
     const uint32_t t = (uint32_t)__builtin_ctzll(~m);            // ancestors that move down
-    if ((uint32_t)lane < t) a[(n >> lane) - 1] = x;
-    if ((uint32_t)lane == t) a[(n >> t) - 1] = v;
+    // lanes below t hand their ancestor down one level, lane t drops the new element into the gap
+    if ((uint32_t)lane <= t) a[(n >> lane) - 1] = (uint32_t)lane < t ? x : v;
 }
 
 // Returns the new root (valid when n > 1).
@@ -226,15 +225,15 @@ __device__ __forceinline__ uint2 heap_pop_wave(uint2* a, uint32_t n /* size befo
     const uint32_t sh = d - (uint32_t)lane;                                  // meaningful for lane < d
     const uint32_t my_to = (p >> (sh & 31u)) - 1, my_from = (p >> ((sh - 1) & 31u)) - 1;
     uint2 x = make_uint2(0, 0);
-    bool c = false;
-    if ((uint32_t)lane < d) { x = a[my_from]; c = Ord::before(x, v); }
-    const unsigned long long cm = __ballot(c);
+    if ((uint32_t)lane < d) x = a[my_from];
+    const unsigned long long cm = __ballot((uint32_t)lane < d && Ord::before(x, v));
     uint32_t s = 0;                                       // path elements (from the leaf up) that stay put
     if (d > 0) { s = (uint32_t)__builtin_clzll(~(cm << (64 - d))); if (s > d) s = d; }
     const uint32_t moved = d - s;
-    if ((uint32_t)lane < moved) a[my_to] = x;
-    if (s == 0) { if (lane == 0) a[cur] = v; }
-    else if ((uint32_t)lane == moved) a[my_to] = v;
+    // the first `moved` path elements climb one step; the saved last element lands on step `moved`
+    // (for moved == d that is the end of the path, `cur`)
+    if ((uint32_t)lane <= moved) a[my_to] = (uint32_t)lane < moved ? x : v;
+    (void)cur;
     // new root: the first path element if it moved up, else the re-inserted value
     uint2 root;
     root.x = moved > 0 ? rfl(x.x) : v.x;
