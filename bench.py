@@ -295,6 +295,20 @@ def main():
         torch.cuda.synchronize()
         kern_ms = float(np.mean([a.elapsed_time(b) for a, b in kev]))
     achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
+    # second denominator, measured now: what a plain device-to-device copy of 1 GiB moves (read + write)
+    copy_gbs = None
+    if rank == 0:
+        ca = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+        cb = torch.empty_like(ca)
+        cb.copy_(ca)
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record()
+        for _ in range(5):
+            cb.copy_(ca)
+        c1.record()
+        torch.cuda.synchronize()
+        copy_gbs = 5 * 2 * ca.numel() * 4 / (c0.elapsed_time(c1) * 1e-3) / 1e9
+        del ca, cb
     # HBM bytes per launch from the PMC passes of tools/pmc_passes.sh over this same workload
     # (FETCH_SIZE doubled as the gfx950 counter requires, plus WRITE_SIZE); a profile of
     # another workload does not apply
@@ -356,6 +370,14 @@ def main():
                        "sample": f"first {ns} queries, ef={ef}, min of {rec['passes']} passes, 1 thread; unmodified reference binary, "
                                  f"index read by its own loadGraph from the file this library saved",
                        "gpu_top10_equals_reference_on_first": npar, "parity": same}
+                # the reference object cannot be shared between threads (a query writes to it, src/hnsw.cpp:380), so the
+                # many-core figure is the CPU restatement's: one private scratch per thread over the shared flat graph
+                nt = min(16, os.cpu_count() or 1)
+                idx = oracle.OracleIndex(h.export_flat(), base)
+                t0 = time.perf_counter()
+                idx.search(queries, ef, out_k=k, threads=nt, dist_mode=1 if args.dist == "scalar" else 0, key_mode=0)
+                cpu["all_cores"] = {"value": round(nq / (time.perf_counter() - t0), 1), "unit": "queries/s", "cores": nt, "kind": "port",
+                                    "sample": f"all {nq} queries once, {nt} threads (CPU restatement, bit-equal to the reference)"}
             except (subprocess.TimeoutExpired, subprocess.CalledProcessError) as e:
                 ref_note = (f"reference binary did not finish ({type(e).__name__}); its visited table never returns once a "
                             f"query visits 16384 nodes (src/hnsw.h:90-107)")
@@ -395,6 +417,8 @@ def main():
                        "ground_truth": dict(gt_info, method="exact brute force, f32-input MFMA kernel of this library")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "measured_copy_gbs": round(copy_gbs, 1) if copy_gbs else None,
+                         "frac_of_measured_copy": round(achieved / copy_gbs, 4) if copy_gbs else None,
                          "kernel": "hnsw_search_kernel", "kernel_ms": round(kern_ms, 4),
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "bytes_per_query": round(bytes_per_launch / nq, 1)},
