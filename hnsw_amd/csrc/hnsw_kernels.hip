@@ -1239,16 +1239,25 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
         const bool std_heap = (flags & HNSW_AMD_W_STD_HEAP) != 0 || ef > 256;
         if (!std_heap && a.cap_w > a.cap_c) throw std::logic_error("search: W does not fit the space it borrows for the final sort");
         size_t lds = search_lds_bytes(a, std_heap);
+        const int wr = std_heap ? 0 : (ef <= 64 ? 1 : (ef <= 128 ? 2 : 4));
+        const SearchKernel kern = pick_kernel(scalar, wr, u8 ? 1 : (q8 ? 2 : 0));
         {
-            // 16-bit visited slots where they let a CU hold more queries (LDS is the limit for larger ef;
-            // 16 per CU is what the registers allow anyway)
+            // 16-bit visited slots where they let a CU hold more queries (what the kernel's registers and the
+            // LDS size allow together is asked from the runtime)
             uint32_t rb = 0, slots = 0;
             if (!getenv("HNSW_AMD_VISITED32") && visited16_shape(g.n, t.want_visit, rb, slots)) {
                 SearchArgs b = a;
                 b.hash_size = slots; b.vis_rb = rb;
                 const size_t lds16 = search_lds_bytes(b, std_heap);
-                const size_t occ32 = std::min<size_t>(16, (size_t)163840 / lds), occ16 = std::min<size_t>(16, (size_t)163840 / lds16);
-                if (occ16 > occ32) { a = b; lds = lds16; }
+                int occ32 = 0, occ16 = 0;
+                if (lds <= 65536 && lds16 <= 65536) {
+                    HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ32, reinterpret_cast<const void*>(kern), 64, lds));
+                    HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ16, reinterpret_cast<const void*>(kern), 64, lds16));
+                } else {
+                    occ32 = (int)(163840 / lds); occ16 = (int)(163840 / lds16);
+                }
+                // (beyond 16 queries per CU the cheaper 32-bit probe wins: measured on the byte-row kernel, 16 -> 20)
+                if (occ16 > occ32 && occ32 < 16) { a = b; lds = lds16; }
             }
         }
         if (lds > (size_t)max_lds) {
@@ -1257,9 +1266,6 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
         }
         a.fail_count = cur; a.fail_list = cur + 1;
         HIP_CHECK(hipMemsetAsync(cur, 0, 4, stream));
-        void (*kern)(SearchArgs);
-        const int wr = std_heap ? 0 : (ef <= 64 ? 1 : (ef <= 128 ? 2 : 4));
-        kern = pick_kernel(scalar, wr, u8 ? 1 : (q8 ? 2 : 0));
         if (lds > 32768)
             HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         if (const char* pad = getenv("HNSW_AMD_LDS_PAD")) lds += (size_t)atoi(pad);      // occupancy experiments
