@@ -209,16 +209,17 @@ __device__ __forceinline__ uint2 heap_pop_wave(uint2* a, uint32_t n /* size befo
     }
     // Walk the hole down on the scalar unit, in 1-based indices: the children of p are 2p (left) and
     // 2p+1 (right), so the path is the bit string of the final index and step k of it is a shift.
-    uint32_t p = 1, d = 0;
+    uint32_t idx = 0;                                         // 0-based node the hole is at
     {
         const uint32_t lim0 = nint < 63u ? nint : 63u;       // nodes 0..62 (six levels) are all in m0
-        while (p - 1 < lim0) { p = 2 * p + 1 - (uint32_t)((m0 >> (p - 1)) & 1ull); d++; }
-        while (p - 1 < nint) {
-            const uint32_t idx = p - 1;
+        while (idx < lim0) idx = 2 * idx + 2 - (uint32_t)((m0 >> idx) & 1ull);
+        while (idx < nint) {
             const unsigned long long m = idx < 64 ? m0 : (idx < 128 ? m1 : (idx < 192 ? m2 : m3));
-            p = 2 * p + 1 - (uint32_t)((m >> (idx & 63u)) & 1ull); d++;
+            idx = 2 * idx + 2 - (uint32_t)((m >> (idx & 63u)) & 1ull);
         }
     }
+    uint32_t p = idx + 1;                                     // 1-based: a leading 1 followed by one bit per step
+    uint32_t d = 31u - (uint32_t)__clz((int)p);               // steps taken
     if ((len & 1u) == 0 && p - 1 == (len - 2) >> 1) { p = 2 * p; d++; }     // a last node with a left child only
     const uint32_t cur = p - 1;                                              // where the hole ends up
     // lane k owns step k of the path: the element at my_from moves up to my_to
