@@ -101,3 +101,25 @@ def test_other_list_lengths_match_oracle(M, kind, flags):
             np.savez(os.path.join(out, f"mismatch_M{M}_{kind}_ef{ef}_flags{flags}.npz"), ids=ids, dist=dist, cnt=cnt, st=st,
                      oi=oi, od=od, oc=oc, ost=ost, **fg.to_npz_dict())
             raise
+
+
+@pytest.mark.parametrize("d", [5, 19, 33, 130, 257])
+def test_odd_dimensions_match_oracle(d):
+    """Row lengths that are no multiple of 4, 16 or 32: the shipped distance drops the last d mod 16 dims (all of
+    them for d < 16: every distance is 0), the scalar one uses every dim with its fused last d mod 4."""
+    n, nq = 3000, 100
+    base = datagen.make("sift", n, seed=12, d=d)
+    q = datagen.make("sift", nq, seed=12, stream=1, d=d)
+    h = HNSW(8, 8, 40)
+    h.init(d, n)
+    h.insert_batch(base, threads=8)
+    fg = h.export_flat()
+    idx = oracle.OracleIndex(fg, base)
+    for flags, dm in ((capi.DIST_SSE, oracle.DIST_SSE), (capi.DIST_SCALAR, oracle.DIST_SCALAR)):
+        for ef in (10, 70):
+            ids, dist, cnt, st = h.search_batch(q, ef, flags=flags, stats=True)
+            oi, od, oc, ost = idx.search(q, ef, dist_mode=dm, stats=True, threads=4)
+            assert np.array_equal(cnt, oc)
+            assert_same_results(ids, dist, oi, od, what=f"d={d} flags={flags} ef={ef}")
+            for field in st.dtype.names:
+                assert np.array_equal(st[field], ost[field]), f"d={d} flags={flags} ef={ef}: counter {field}"
