@@ -387,9 +387,11 @@ __device__ __forceinline__ void consume_item_sse(const float* qp, uint32_t nld, 
     for (int t = 0; t < 8; t++)
         if (FULL || (uint32_t)t < nld) {
             const float4 q = *reinterpret_cast<const float4*>(qp + 32 * (t >> 1) + 4 * (t & 1));
-            const float t0 = v[t].x - q.x, t1 = v[t].y - q.y, t2 = v[t].z - q.z, t3 = v[t].w - q.w;
-            a = __builtin_fmaf(t0, t0, a); a = __builtin_fmaf(t1, t1, a);
-            a = __builtin_fmaf(t2, t2, a); a = __builtin_fmaf(t3, t3, a);
+            // the differences two at a time (packed f32 subtract: same IEEE result per element); the chain itself is serial
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            const f2 dlo = f2{v[t].x, v[t].y} - f2{q.x, q.y}, dhi = f2{v[t].z, v[t].w} - f2{q.z, q.w};
+            a = __builtin_fmaf(dlo.x, dlo.x, a); a = __builtin_fmaf(dlo.y, dlo.y, a);
+            a = __builtin_fmaf(dhi.x, dhi.x, a); a = __builtin_fmaf(dhi.y, dhi.y, a);
         }
 }
 
@@ -411,10 +413,11 @@ __device__ __forceinline__ void consume_item_u8(const float* qp, uint32_t nwords
         if (FULL || (uint32_t)w < nwords) {
             const float4 q = *reinterpret_cast<const float4*>(qp + 4 * w);
             const uint32_t word = u4_get(v[w >> 2], w & 3);
-            const float t0 = (float)(word & 0xFFu) - q.x, t1 = (float)((word >> 8) & 0xFFu) - q.y;
-            const float t2 = (float)((word >> 16) & 0xFFu) - q.z, t3 = (float)(word >> 24) - q.w;
-            a = __builtin_fmaf(t0, t0, a); a = __builtin_fmaf(t1, t1, a);
-            a = __builtin_fmaf(t2, t2, a); a = __builtin_fmaf(t3, t3, a);
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            const f2 dlo = f2{(float)(word & 0xFFu), (float)((word >> 8) & 0xFFu)} - f2{q.x, q.y};
+            const f2 dhi = f2{(float)((word >> 16) & 0xFFu), (float)(word >> 24)} - f2{q.z, q.w};
+            a = __builtin_fmaf(dlo.x, dlo.x, a); a = __builtin_fmaf(dlo.y, dlo.y, a);
+            a = __builtin_fmaf(dhi.x, dhi.x, a); a = __builtin_fmaf(dhi.y, dhi.y, a);
         }
 }
 
