@@ -59,6 +59,8 @@ def main():
                     help="N > 1: sharded = the base split into N sub-graphs, every query on every GPU, all-gather + merge "
                          "(fixed total work); replicated = the whole index on every GPU, each with its own batch of "
                          "--queries queries and no collective in the data path (work grows with N)")
+    ap.add_argument("--no-alongside", action="store_true",
+                    help="N > 1, sharded mode: skip the replicated-index measurement reported next to the sharded one")
     ap.add_argument("--sweep", default="", help="comma-separated ef values: report recall and QPS for each instead of one operating point")
     args = ap.parse_args()
 
@@ -403,6 +405,77 @@ def main():
             if ref_note:
                 cpu["note"] = ref_note
 
+    # ---- N > 1, sharded: the replicated layout measured next to it (whole index on every GPU, a batch of
+    #      queries per rank, no collective in the data path; work grows with N) ----
+    alongside = None
+    if world > 1 and parts > 1 and not args.no_alongside and args.n <= 2_000_000:
+        from hnsw_amd.flatgraph import FlatGraph
+        t0 = time.time()
+        fpath = os.path.join(tempfile.gettempdir(), f"hnsw_amd_bench_full_{os.environ.get('MASTER_PORT', '0')}_{args.kind}_{args.n}.npz")
+        full = datagen.make(args.kind, args.n, seed=1, stream=0)
+        hf = HNSW(16, 16, 200, device=local_rank)
+        if rank == 0:                                   # one build for the node, handed over through a local file
+            hf.init(d, args.n)
+            for r0 in range(0, args.n, 500_000):
+                hf.insert_batch(full[r0:r0 + 500_000], threads=args.build_threads)
+                log(f"alongside: inserted {min(args.n, r0 + 500_000)} / {args.n} in {time.time() - t0:.0f}s")
+            np.savez(fpath + ".tmp.npz", **hf.export_flat().to_npz_dict())
+            os.replace(fpath + ".tmp.npz", fpath)
+        dist.barrier()
+        if rank != 0:
+            hf.import_flat(FlatGraph.from_npz(np.load(fpath)), full)
+        dist.barrier()
+        if rank == 0:
+            os.remove(fpath)
+        hf.flags = flags
+        hf.sync_device(local_rank)
+        q_r = datagen.make(args.kind, nq, seed=1, stream=1, row0=rank * nq)
+        qr_t = torch.from_numpy(q_r).to(dev)
+        full_t = torch.from_numpy(full).to(dev)
+        _, gi_r, _ = harness.exact_topk_mfma(full_t, qr_t, k)
+        del full_t
+        gt_r = gi_r.cpu().numpy()
+        stream = torch.cuda.current_stream().cuda_stream
+
+        def rstep(ef_):
+            hf.search_batch_device(qr_t.data_ptr(), nq, ef_, k, out_ids.data_ptr(), out_dist.data_ptr(), cnt_t.data_ptr(), 0, stream, flags)
+
+        ef_r, rec_r = harness.REFERENCE_EF_SWEEP[-1], 0.0
+        for e in ([args.ef] if args.ef else harness.REFERENCE_EF_SWEEP):
+            rstep(e)
+            torch.cuda.synchronize()
+            rec_r = harness.recall_at_k(out_ids.cpu().numpy().astype(np.int64) & 0xFFFFFFFF, gt_r, k)
+            ef_r = e
+            if args.ef or rec_r >= args.target_recall:
+                break
+        et = torch.tensor([float(ef_r)], dtype=torch.float64, device=dev)
+        dist.all_reduce(et, op=dist.ReduceOp.MAX)       # every rank at the largest ef any rank needed
+        ef_r = int(et.item())
+        rstep(ef_r)
+        torch.cuda.synchronize()
+        rec_r = harness.recall_at_k(out_ids.cpu().numpy().astype(np.int64) & 0xFFFFFFFF, gt_r, k)
+        for _ in range(args.warmup):
+            rstep(ef_r)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            rstep(ef_r)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t1
+        tt = torch.tensor([el, rec_r], dtype=torch.float64, device=dev)
+        mx = tt.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        el = float(mx[0].item())
+        alongside = {"layout": f"whole index on each of {world} GPUs, {nq} queries per GPU, no collective",
+                     "value": round(world * nq * args.steps / el, 1), "unit": "queries/s", "scaling": "weak",
+                     "ms_per_step": round(el / args.steps * 1e3, 4), "ef": ef_r, "recall_at_10": round(float(tt[1].item()) / world, 4)}
+        log(f"alongside (replicated): {alongside} in {time.time() - t0:.0f}s")
+
     if rank == 0:
         out = {
             "metric": "queries/s at recall@10>=0.95, HNSW search, SIFT-128-shaped 1M base / 10k queries",
@@ -424,6 +497,8 @@ def main():
                          "bytes_per_query": round(bytes_per_launch / nq, 1)},
             "cpu_baseline": cpu,
         }
+        if alongside is not None:
+            out["replicated_alongside"] = alongside
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
