@@ -59,3 +59,33 @@ def test_cpp_drop_in_class_runs_the_reference_style_driver(tmp_path):
     ids, _, _ = h.search_batch(q, 200, out_k=11)
     from hnsw_amd.harness import reference_precision
     assert abs(reference_precision(ids, gt, 10) - one) < 1e-9
+
+
+def test_cpp_hdf5_create_and_query(tmp_path):
+    """The reference's HDF5 mode (create(file, "train") + query(file, "test", "neighbors", ef), src/main.cpp:140-160)
+    through include/hnsw_amd.hpp on an ann-benchmarks-shaped file: the precision it prints equals the one the
+    Python mirror computes on the same data."""
+    from tests import hdf5_writer
+    if not hdf5_writer.available():
+        pytest.skip("libhdf5 not found")
+    exe = os.path.join(ROOT, "examples", "hdf5_test")
+    if not os.path.exists(exe):
+        pytest.fail("examples/hdf5_test is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    n, nq = 4000, 150
+    base = datagen.make("sift", n, seed=4)
+    q = datagen.make("sift", nq, seed=4, stream=1)
+    from oracle import oracle
+    gt = oracle.bruteforce(base, q, 100).astype(np.int32)
+    path = str(tmp_path / "set.hdf5")
+    hdf5_writer.write(path, {"train": base, "test": q, "neighbors": gt})
+    out = subprocess.run([exe, path, "1", "20", "100"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    got = [float(l.split()[1].rstrip(",")) for l in out.stdout.splitlines() if l.startswith("Precision:")]
+    assert len(got) == 2 and got[1] > 0.99 and got[0] <= got[1]
+    h = HNSW(16, 16, 200)
+    h.init(128, n)
+    h.insert_batch(base)            # one thread, like the driver: the same graph
+    from hnsw_amd.harness import reference_precision
+    for ef, p in zip((20, 100), got):
+        ids, _, _ = h.search_batch(q, ef, out_k=11)
+        assert abs(reference_precision(ids, gt, 10) - p) < 1e-6
