@@ -122,7 +122,20 @@ public:
     // (n x d floats) and insert every row.  query: read the query and ground-truth datasets,
     // search all queries as one GPU batch and return the reference's precision figure
     // (ground-truth top-10 found among the first 11 results).
-    void create(const char* filename, const char* datasetname, int threads = 1)
+    // normalize = true scales every row (and later every query) to unit length first: the reference has no
+    // metric switch and searches angular sets as raw L2 (src/main.cpp:16,29,42 read the arrays as they are);
+    // on unit vectors squared L2 ranks like the angle, which is what such a file's "neighbors" were computed with.
+    static void normalizeRows(float* rows, size_t n, size_t d)
+    {
+        for (size_t i = 0; i < n; i++) {
+            double s = 0.0;
+            for (size_t j = 0; j < d; j++) s += (double)rows[i * d + j] * rows[i * d + j];
+            if (s <= 0.0) continue;
+            const float inv = (float)(1.0 / std::sqrt(s));
+            for (size_t j = 0; j < d; j++) rows[i * d + j] *= inv;
+        }
+    }
+    void create(const char* filename, const char* datasetname, int threads = 1, bool normalize = false)
     {
         hsize_t dims[2] = {0, 0};
         hdfReader::getDimensions(filename, datasetname, &dims);
@@ -131,9 +144,10 @@ public:
         init((uint32_t)dims[1], (uint32_t)dims[0]);
         std::vector<float> data((size_t)dims[0] * dims[1]);
         hdfReader::readData(filename, datasetname, data.data());
+        if (normalize) normalizeRows(data.data(), (size_t)dims[0], (size_t)dims[1]);
         insertBatch(data.data(), (uint32_t)dims[0], threads);
     }
-    double query(const char* filename, const char* querydatasetname, const char* resultdatasetname, int ef)
+    double query(const char* filename, const char* querydatasetname, const char* resultdatasetname, int ef, bool normalize = false)
     {
         hsize_t dq[2] = {0, 0}, dr[2] = {0, 0};
         hdfReader::getDimensions(filename, querydatasetname, &dq);
@@ -142,6 +156,7 @@ public:
         std::vector<float> q((size_t)dq[0] * dq[1]);
         std::vector<int> gt((size_t)dr[0] * dr[1]);
         hdfReader::readData(filename, querydatasetname, q.data());
+        if (normalize) normalizeRows(q.data(), (size_t)dq[0], (size_t)dq[1]);
         hdfReader::readData(filename, resultdatasetname, gt.data());
         const uint32_t k = 10, take = k + 1, nq = (uint32_t)dq[0];
         if (dr[1] < k) throw std::runtime_error("query: ground truth narrower than k");

@@ -78,7 +78,7 @@ def test_cpp_hdf5_create_and_query(tmp_path):
     gt = oracle.bruteforce(base, q, 100).astype(np.int32)
     path = str(tmp_path / "set.hdf5")
     hdf5_writer.write(path, {"train": base, "test": q, "neighbors": gt})
-    out = subprocess.run([exe, path, "1", "20", "100"], capture_output=True, text=True, timeout=300)
+    out = subprocess.run([exe, path, "1", "l2", "20", "100"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
     got = [float(l.split()[1].rstrip(",")) for l in out.stdout.splitlines() if l.startswith("Precision:")]
     assert len(got) == 2 and got[1] > 0.99 and got[0] <= got[1]
@@ -89,3 +89,27 @@ def test_cpp_hdf5_create_and_query(tmp_path):
     for ef, p in zip((20, 100), got):
         ids, _, _ = h.search_batch(q, ef, out_k=11)
         assert abs(reference_precision(ids, gt, 10) - p) < 1e-6
+
+
+def test_cpp_hdf5_angular_set_is_normalised_on_load(tmp_path):
+    """An angular file (rows of arbitrary length, "neighbors" by cosine): with `angular` the driver scales rows and
+    queries to unit length, on which squared L2 ranks like the angle; without it the raw-L2 search misses them."""
+    from tests import hdf5_writer
+    if not hdf5_writer.available():
+        pytest.skip("libhdf5 not found")
+    exe = os.path.join(ROOT, "examples", "hdf5_test")
+    n, nq = 4000, 100
+    rng = np.random.default_rng(5)
+    unit = datagen.make("glove", n + nq, seed=5)
+    raw = (unit * rng.uniform(0.2, 5.0, size=(n + nq, 1))).astype(np.float32)       # same directions, other lengths
+    base, q = raw[:n], raw[n:]
+    cos = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float64) @ (base / np.linalg.norm(base, axis=1, keepdims=True)).astype(np.float64).T
+    gt = np.argsort(-cos, axis=1)[:, :100].astype(np.int32)
+    path = str(tmp_path / "angular.hdf5")
+    hdf5_writer.write(path, {"train": base, "test": q, "neighbors": gt})
+    prec = {}
+    for metric in ("angular", "l2"):
+        out = subprocess.run([exe, path, "4", metric, "100"], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr
+        prec[metric] = [float(l.split()[1].rstrip(",")) for l in out.stdout.splitlines() if l.startswith("Precision:")][0]
+    assert prec["angular"] > 0.9 and prec["l2"] < 0.7, prec
