@@ -61,6 +61,9 @@ def main():
                          "--queries queries and no collective in the data path (work grows with N)")
     ap.add_argument("--no-alongside", action="store_true",
                     help="N > 1, sharded mode: skip the replicated-index measurement reported next to the sharded one")
+    ap.add_argument("--build-keys", default="int32", choices=["int32", "float"],
+                    help="float: the construction searches use float candidate keys (a regular HNSW graph, not the reference's; "
+                         "several times faster to build on unit-norm data)")
     ap.add_argument("--sweep", default="", help="comma-separated ef values: report recall and QPS for each instead of one operating point")
     args = ap.parse_args()
 
@@ -103,7 +106,7 @@ def main():
     # ---- build (host, concurrent inserts) or load from the cache directory ----
     h = HNSW(16, 16, 200, device=local_rank)
     cache = os.environ.get("HNSW_AMD_BENCH_CACHE")
-    cpath = os.path.join(cache, f"{args.kind}_n{args.n}_s{parts}_r{prank}.npz") if cache else None
+    cpath = os.path.join(cache, f"{args.kind}_n{args.n}_s{parts}_r{prank}{'_fk' if args.build_keys == 'float' else ''}.npz") if cache else None
     t0 = time.time()
     if cpath and os.path.exists(cpath):
         from hnsw_amd.flatgraph import FlatGraph
@@ -111,6 +114,8 @@ def main():
         log(f"rank {rank}: graph loaded from {cpath} in {time.time() - t0:.1f}s")
     else:
         h.init(d, hi - lo)
+        if args.build_keys == "float":
+            h.set_build_float_keys(True)
         step_rows = 500_000       # in pieces, so a long build keeps reporting progress
         for r0 in range(0, hi - lo, step_rows):
             h.insert_batch(base[r0:r0 + step_rows], threads=args.build_threads)
@@ -486,7 +491,7 @@ def main():
                                    f"keys={args.keys}, rows={args.rows}" + (f", {world} shards + RCCL all-gather + device merge" if parts > 1 else "")
                                    + (f", index replicated on {world} GPUs, {nq} queries each" if world > 1 and parts == 1 else ""),
                        "ef": ef, "recall_at_10": round(recall, 4), "reference_precision_top11": prec_ref,
-                       "ef_sweep": sweep, "build_s": round(build_s, 1), "build_threads": args.build_threads,
+                       "ef_sweep": sweep, "build_s": round(build_s, 1), "build_threads": args.build_threads, "build_keys": args.build_keys,
                        "ground_truth": dict(gt_info, method="exact brute force, f32-input MFMA kernel of this library")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

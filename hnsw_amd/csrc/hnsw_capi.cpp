@@ -109,6 +109,11 @@ int hnsw_amd_insert_batch(hnsw_amd_index* h, const float* rows, uint32_t n, int 
     return guarded([&] { REQUIRE(h && (rows || n == 0), "insert_batch: NULL argument"); h->host.insert_batch(rows, n, threads); });
 }
 
+int hnsw_amd_set_build_float_keys(hnsw_amd_index* h, int on)
+{
+    return guarded([&] { REQUIRE(h, "set_build_float_keys: index is NULL"); h->host.build_float_keys_ = on != 0; });
+}
+
 int hnsw_amd_sync_device(hnsw_amd_index* h, int device)
 {
     return guarded([&] {

@@ -217,7 +217,12 @@ void HostIndex::search_layer(int layer, const float* q, int ef, Scratch& s)
     LayerStore& L = layers_[layer];
     auto& W = s.W; auto& C = s.C;
     C.clear();
-    for (auto& n : W) { C.push_back(Cand{trunc_key(n.distance), n.slot}); s.test_and_set(n.node_order); }
+    // candidate keys: the reference's int32 truncation, or (option) the float distance itself, stored as its bit
+    // pattern: non-negative floats order like their bit patterns read as int32
+    const bool fk = build_float_keys_;
+    auto key_of = [fk](float dist) -> int32_t { int32_t b; std::memcpy(&b, &dist, 4); return fk ? b : trunc_key(dist); };
+    auto key_as_float = [fk](int32_t key) -> float { float v; std::memcpy(&v, &key, 4); return fk ? v : (float)key; };
+    for (auto& n : W) { C.push_back(Cand{key_of(n.distance), n.slot}); s.test_and_set(n.node_order); }
     std::make_heap(W.begin(), W.end(), WLess());
     std::make_heap(C.begin(), C.end(), CGreater());
     float f = W.front().distance;
@@ -227,7 +232,7 @@ void HostIndex::search_layer(int layer, const float* q, int ef, Scratch& s)
         Cand c = C.front();
         std::pop_heap(C.begin(), C.end(), CGreater());
         C.pop_back();
-        if ((float)c.key > f) break;
+        if (key_as_float(c.key) > f) break;
         uint32_t m = 0;
         {
             SpinGuard g(MT ? &locks_[layer][c.slot] : nullptr);
@@ -248,7 +253,7 @@ void HostIndex::search_layer(int layer, const float* q, int ef, Scratch& s)
         for (j = 0; j < m; j++) {
             const float dist = s.dist[j];
             if (dist < f || W.size() < (size_t)ef) {
-                C.push_back(Cand{trunc_key(dist), s.slots[j]});
+                C.push_back(Cand{key_of(dist), s.slots[j]});
                 std::push_heap(C.begin(), C.end(), CGreater());
                 W.push_back(Neighbor{dist, s.ids[j], s.slots[j]});
                 std::push_heap(W.begin(), W.end(), WLess());

@@ -60,6 +60,7 @@ public:
     uint32_t vector_size_ = 0;
     std::vector<LayerStore> layers_;
     std::vector<float> vector_data_;   // max_node_count_ x vector_size_, row = node_order
+    bool build_float_keys_ = false;    // construction searches keyed by the float distance instead of its int32 truncation
     uint64_t version_ = 0;             // bumped by every mutation (device copy refresh)
 
     HostIndex(int M, int Mmax, int efConstruction);

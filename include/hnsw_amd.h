@@ -111,6 +111,12 @@ int hnsw_amd_insert(hnsw_amd_index* h, const float* q);
  * sequential inserts; threads > 1: concurrent inserts (a valid HNSW graph of the same
  * construction rule, but not the reference's exact adjacency). */
 int hnsw_amd_insert_batch(hnsw_amd_index* h, const float* rows, uint32_t n, int threads);
+/* Construction option with no counterpart in the reference: key the candidate heap of the searches that insert()
+ * runs by the float distance instead of the reference's int32 truncation (src/hnsw.cpp:727,767).  Off by default
+ * (the sequential build then reproduces the reference's graph).  On unit-norm data the truncated keys are all 0..3,
+ * the construction search never stops early, and turning this on makes the build several times faster; the result
+ * is a regular HNSW graph, not the reference's adjacency. */
+int hnsw_amd_set_build_float_keys(hnsw_amd_index* h, int on);
 
 /* HNSW::aproximateKnn(float* q, int k, int ef) — src/hnsw.cpp:373-449.  The reference leaves
  * its result in the public member W_ (up to ef entries, ascending squared-L2 distance; k is

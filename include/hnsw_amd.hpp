@@ -80,6 +80,8 @@ public:
     void insert(float* q) { check(hnsw_amd_insert(h_, q)); actual_node_count_++; }
     // the driver's insert loop (src/main.cpp:207-210) in one call; threads > 1 builds concurrently
     void insertBatch(const float* rows, uint32_t n, int threads) { check(hnsw_amd_insert_batch(h_, rows, n, threads)); refresh(); }
+    // construction searches keyed by the float distance instead of the int32 truncation (see hnsw_amd.h)
+    void setBuildFloatKeys(bool on) { check(hnsw_amd_set_build_float_keys(h_, on ? 1 : 0)); }
 
     // src/hnsw.cpp:373-449: result in W_, up to ef entries ascending; k is ignored as upstream
     void aproximateKnn(float* q, int k, int ef)

@@ -97,3 +97,30 @@ def test_concurrent_build_keeps_every_list_well_formed():
         if rep % 8 == 0:
             ids, _, _ = oracle.OracleIndex(fg, base).search(q, 64, out_k=10, key_mode=oracle.KEYS_FLOAT, threads=4)
             assert recall_at_k(ids, gt, 10) > 0.9
+
+
+def test_float_build_keys_change_nothing_on_integer_data_and_work_on_unit_norm_data():
+    """The construction option keys the insert-time searches by the float distance.  On integer-valued data the
+    int32 truncation is the identity, so the sequential build still reproduces the reference's graph; on unit-norm
+    data (truncated keys all 0..3) it gives another, regular HNSW graph - checked by recall."""
+    import numpy as np
+    from hnsw_amd import HNSW, datagen
+    from oracle import oracle
+    from tests.helpers import Golden, recall_at_k
+    g = Golden("int_d32_n2000")
+    h = HNSW(*g.meta["ctor"])
+    h.init(g.meta["d"], g.meta["n"])
+    h.set_build_float_keys(True)
+    for row in g.base:
+        h.insert(row)
+    assert h.export_flat().adjacency_hash() == g.meta["adjacency_hash"]
+    n = 20000
+    base = datagen.make("deep", n, seed=13)
+    q = datagen.make("deep", 100, seed=13, stream=1)
+    gt = oracle.bruteforce(base, q, 10, threads=4)
+    h2 = HNSW(16, 16, 100)
+    h2.init(96, n)
+    h2.set_build_float_keys(True)
+    h2.insert_batch(base, threads=8)
+    ids, _, _ = oracle.OracleIndex(h2.export_flat(), base).search(q, 64, out_k=10, key_mode=oracle.KEYS_FLOAT, threads=4)
+    assert recall_at_k(ids, gt, 10) > 0.95

@@ -18,6 +18,9 @@ b)
   run gist960_1m --kind gist --base-size 1000000 --queries 1000 --cpu-baseline none &&
   run deep96_4m_single_shard --kind deep --base-size 4000000 --cpu-baseline none
   ;;
+d)
+  run deep96_12.5M_single_shard_float_build_keys --kind deep --base-size 12500000 --build-keys float --cpu-baseline none
+  ;;
 c)
   run glove100_1.18M_sse_float_sweep --kind glove --base-size 1183514 --keys float --sweep 20,40,60,100 --cpu-baseline none &&
   run glove100_1.18M_sse_float_q8_sweep --kind glove --base-size 1183514 --keys float --rows q8 --sweep 20,40,60,100 --cpu-baseline none &&
