@@ -57,96 +57,12 @@ __device__ __forceinline__ int32_t trunc_key(float f)
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ float rflf(float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); }
 
-// ---- W: max-heap on the float distance; entries (dist bits, id).  libstdc++ __push_heap /
-// __adjust_heap with comp(a,b) = a.dist < b.dist (reference src/node.h:48-52). ----
-__device__ __forceinline__ void w_push(uint2* a, uint32_t n)
-{
-    uint2 v = a[n - 1];
-    float vd = __uint_as_float(v.x);
-    uint32_t hole = n - 1;
-    while (hole > 0) {
-        uint32_t parent = (hole - 1) >> 1;
-        uint2 p = a[parent];
-        if (!(__uint_as_float(p.x) < vd)) break;
-        a[hole] = p; hole = parent;
-    }
-    a[hole] = v;
-}
-
-__device__ __forceinline__ void w_pop(uint2* a, uint32_t n)
-{
-    if (n <= 1) return;
-    uint32_t len = n - 1;
-    uint2 v = a[len];
-    float vd = __uint_as_float(v.x);
-    a[len] = a[0];
-    uint32_t hole = 0, child = 0;
-    while (child < (len - 1) >> 1) {
-        child = 2 * (child + 1);
-        uint2 r = a[child], l = a[child - 1];
-        if (__uint_as_float(r.x) < __uint_as_float(l.x)) { child--; r = l; }
-        a[hole] = r; hole = child;
-    }
-    if ((len & 1) == 0 && child == (len - 2) >> 1) {
-        child = 2 * (child + 1);
-        a[hole] = a[child - 1]; hole = child - 1;
-    }
-    while (hole > 0) {
-        uint32_t parent = (hole - 1) >> 1;
-        uint2 p = a[parent];
-        if (!(__uint_as_float(p.x) < vd)) break;
-        a[hole] = p; hole = parent;
-    }
-    a[hole] = v;
-}
-
-// ---- C: min-heap on an int32 key; entries (key, id); comp(a,b) = a.key > b.key
-// (reference src/hnsw.h:210-215). ----
-__device__ __forceinline__ void c_push(uint2* a, uint32_t n)
-{
-    uint2 v = a[n - 1];
-    int32_t vk = (int32_t)v.x;
-    uint32_t hole = n - 1;
-    while (hole > 0) {
-        uint32_t parent = (hole - 1) >> 1;
-        uint2 p = a[parent];
-        if (!((int32_t)p.x > vk)) break;
-        a[hole] = p; hole = parent;
-    }
-    a[hole] = v;
-}
-
-__device__ __forceinline__ void c_pop(uint2* a, uint32_t n)
-{
-    if (n <= 1) return;
-    uint32_t len = n - 1;
-    uint2 v = a[len];
-    int32_t vk = (int32_t)v.x;
-    a[len] = a[0];
-    uint32_t hole = 0, child = 0;
-    while (child < (len - 1) >> 1) {
-        child = 2 * (child + 1);
-        uint2 r = a[child], l = a[child - 1];
-        if ((int32_t)r.x > (int32_t)l.x) { child--; r = l; }
-        a[hole] = r; hole = child;
-    }
-    if ((len & 1) == 0 && child == (len - 2) >> 1) {
-        child = 2 * (child + 1);
-        a[hole] = a[child - 1]; hole = child - 1;
-    }
-    while (hole > 0) {
-        uint32_t parent = (hole - 1) >> 1;
-        uint2 p = a[parent];
-        if (!((int32_t)p.x > vk)) break;
-        a[hole] = p; hole = parent;
-    }
-    a[hole] = v;
-}
-
 // ---------------------------------------------------------------------------------------
-// The same two libstdc++ routines executed by the whole wavefront in a constant number of
-// LDS round trips instead of one per tree level.  They leave the array exactly as
-// std::push_heap / std::pop_heap do:
+// The heaps: W is a max-heap on the float distance (entries (dist bits, id), comp(a,b) = a.dist < b.dist,
+// reference src/node.h:48-52), C a min-heap on an int32 key (entries (key, id), comp(a,b) = a.key > b.key,
+// src/hnsw.h:210-215).  libstdc++'s __push_heap / __adjust_heap are executed by the whole wavefront in a
+// constant number of LDS round trips instead of one per tree level (below the eighth level of a very
+// large heap: one per level).  They leave the array exactly as std::push_heap / std::pop_heap do:
 //  - push: the new element climbs the fixed chain of ancestors of index n-1 while
 //    comp(ancestor, value); lane k owns ancestor k, one ballot gives the climb length.
 //  - pop: __adjust_heap first walks the hole from the root to a leaf choosing, at every
@@ -177,7 +93,6 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t x)
     return __builtin_amdgcn_readlane(x, 63);
 }
 
-constexpr uint32_t kWaveHeapMax = 513;   // larger heaps use the one-lane routines
 
 template <class Ord>
 __device__ __forceinline__ void heap_push_wave(uint2* a, uint32_t n /* size including the new element */, uint2 v, int lane)
@@ -198,24 +113,32 @@ __device__ __forceinline__ uint2 heap_pop_wave(uint2* a, uint32_t n /* size befo
     const uint32_t len = n - 1;
     const uint2 v = a[len];
     const uint32_t nint = (len - 1) >> 1;      // nodes with both children inside [0, len)
-    // bit i of the masks: node i hands the hole to its LEFT child (comp(right, left))
+    // bit i of the masks: node i hands the hole to its LEFT child (comp(right, left)); nodes 0..255, i.e. the
+    // first eight levels, are decided at once
+    const uint32_t nint1 = nint < 256u ? nint : 256u;
     unsigned long long m0 = 0, m1 = 0, m2 = 0, m3 = 0;
     {
         uint32_t i = lane;
-        m0 = __ballot(i < nint && Ord::before(a[2 * i + 2], a[2 * i + 1]));
-        if (nint > 64)  { i = lane + 64;  m1 = __ballot(i < nint && Ord::before(a[2 * i + 2], a[2 * i + 1])); }
-        if (nint > 128) { i = lane + 128; m2 = __ballot(i < nint && Ord::before(a[2 * i + 2], a[2 * i + 1])); }
-        if (nint > 192) { i = lane + 192; m3 = __ballot(i < nint && Ord::before(a[2 * i + 2], a[2 * i + 1])); }
+        m0 = __ballot(i < nint1 && Ord::before(a[2 * i + 2], a[2 * i + 1]));
+        if (nint1 > 64)  { i = lane + 64;  m1 = __ballot(i < nint1 && Ord::before(a[2 * i + 2], a[2 * i + 1])); }
+        if (nint1 > 128) { i = lane + 128; m2 = __ballot(i < nint1 && Ord::before(a[2 * i + 2], a[2 * i + 1])); }
+        if (nint1 > 192) { i = lane + 192; m3 = __ballot(i < nint1 && Ord::before(a[2 * i + 2], a[2 * i + 1])); }
     }
     // Walk the hole down on the scalar unit, in 1-based indices: the children of p are 2p (left) and
     // 2p+1 (right), so the path is the bit string of the final index and step k of it is a shift.
     uint32_t idx = 0;                                         // 0-based node the hole is at
     {
-        const uint32_t lim0 = nint < 63u ? nint : 63u;       // nodes 0..62 (six levels) are all in m0
+        const uint32_t lim0 = nint1 < 63u ? nint1 : 63u;     // nodes 0..62 (six levels) are all in m0
         while (idx < lim0) idx = 2 * idx + 2 - (uint32_t)((m0 >> idx) & 1ull);
-        while (idx < nint) {
+        while (idx < nint1) {
             const unsigned long long m = idx < 64 ? m0 : (idx < 128 ? m1 : (idx < 192 ? m2 : m3));
             idx = 2 * idx + 2 - (uint32_t)((m >> (idx & 63u)) & 1ull);
+        }
+        // a heap of more than 513 entries: the levels below the eighth, one LDS round trip each
+        while (idx < nint) {
+            const uint2 r = a[2 * idx + 2], l = a[2 * idx + 1];
+            const bool left = Ord::before(make_uint2(rfl(r.x), rfl(r.y)), make_uint2(rfl(l.x), rfl(l.y)));
+            idx = 2 * idx + 2 - (left ? 1u : 0u);
         }
     }
     uint32_t p = idx + 1;                                     // 1-based: a leading 1 followed by one bit per step
@@ -776,8 +699,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
                 // the candidate's neighbour list is requested now and arrives while the heap is repaired
                 if (mrow < a.g.deg0) my = a.g.adj0[(size_t)cid * a.g.deg0 + mrow];
                 if (nC > 1) {
-                    if (nC <= kWaveHeapMax) heap_pop_wave<COrder>(C, nC, lane);
-                    else if (lane == 0) c_pop(C, nC);
+                    heap_pop_wave<COrder>(C, nC, lane);
                 }
                 nC--;
                 LDS_SYNC();
@@ -823,8 +745,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
                                 const uint32_t id = __builtin_amdgcn_readlane(my, j);
                                 const uint2 ce = make_uint2(__builtin_amdgcn_readlane(keym, j), id);
                                 nC++;
-                                if (nC <= kWaveHeapMax) heap_push_wave<COrder>(C, nC, ce, lane);
-                                else { if (lane == 0) { C[nC - 1] = ce; c_push(C, nC); } }
+                                heap_push_wave<COrder>(C, nC, ce, lane);
                                 w_sorted_insert<(WR > 0 ? WR : 1)>(wd, wi, ef, db, id, lane);
                                 f = __uint_as_float(w_entry_dist<(WR > 0 ? WR : 1)>(wd, ef - 1));
                                 LDS_SYNC();
@@ -842,34 +763,22 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
                             const uint2 we = make_uint2(__float_as_uint(dist), id);
                             nC++;
                             if (WR > 0) {
-                                if (nC <= kWaveHeapMax) heap_push_wave<COrder>(C, nC, ce, lane);
-                                else { if (lane == 0) { C[nC - 1] = ce; c_push(C, nC); } }
+                                heap_push_wave<COrder>(C, nC, ce, lane);
                                 w_sorted_insert<(WR > 0 ? WR : 1)>(wd, wi, nW, we.x, we.y, lane);
                                 if (nW < ef) nW++;
                                 f = __uint_as_float(w_entry_dist<(WR > 0 ? WR : 1)>(wd, nW - 1));
                                 LDS_SYNC();
                             } else {
                                 nW++;
-                                if (nC <= kWaveHeapMax && nW <= kWaveHeapMax) {
-                                    heap_push_wave<COrder>(C, nC, ce, lane);
-                                    heap_push_wave<WOrder>(W, nW, we, lane);
+                                heap_push_wave<COrder>(C, nC, ce, lane);
+                                heap_push_wave<WOrder>(W, nW, we, lane);
+                                LDS_SYNC();
+                                if (nW > ef) {
+                                    const uint2 root = heap_pop_wave<WOrder>(W, nW, lane);
+                                    nW--;
+                                    f = __uint_as_float(root.x);
                                     LDS_SYNC();
-                                    if (nW > ef) {
-                                        const uint2 root = heap_pop_wave<WOrder>(W, nW, lane);
-                                        nW--;
-                                        f = __uint_as_float(root.x);
-                                        LDS_SYNC();
-                                    } else {
-                                        f = __uint_as_float(W[0].x);
-                                    }
                                 } else {
-                                    if (lane == 0) {
-                                        C[nC - 1] = ce; c_push(C, nC);
-                                        W[nW - 1] = we; w_push(W, nW);
-                                        if (nW > ef) w_pop(W, nW);
-                                    }
-                                    if (nW > ef) nW--;
-                                    LDS_SYNC();
                                     f = __uint_as_float(W[0].x);
                                 }
                             }
