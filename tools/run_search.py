@@ -22,6 +22,7 @@ ap.add_argument("--cache", default="")
 ap.add_argument("--kind", default="sift")
 ap.add_argument("--keys", default="int32")
 ap.add_argument("--rows", default="f32", choices=["f32", "u8"])
+ap.add_argument("--build-keys", default="int32", choices=["int32", "float"])
 a = ap.parse_args()
 base = datagen.make(a.kind, a.n, seed=1)
 q = datagen.make(a.kind, a.nq, seed=1, stream=1)
@@ -30,6 +31,8 @@ if a.cache and os.path.exists(a.cache):
     h.import_flat(FlatGraph.from_npz(np.load(a.cache)), base)
 else:
     h.init(base.shape[1], a.n)
+    if a.build_keys == "float":
+        h.set_build_float_keys(True)
     t = time.time(); h.insert_batch(base, threads=a.threads); print(f"build {time.time()-t:.1f}s", flush=True)
     if a.cache:
         np.savez(a.cache, **h.export_flat().to_npz_dict())
