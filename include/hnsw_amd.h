@@ -61,7 +61,7 @@ enum {
     HNSW_AMD_W_STD_HEAP = 4       /* keep the result list W_ as the libstdc++ binary heap the reference keeps
                                      (src/hnsw.cpp:770-775), so that when several entries tie for the worst
                                      distance the one dropped is the reference's choice as well.  Default (flag
-                                     clear): W_ is an unordered register set, faster; same distances, same ids
+                                     clear): W_ is a sorted list held in registers, faster; same distances, same ids
                                      except possibly among entries exactly tied with the worst kept distance. */
 };
 
