@@ -48,7 +48,7 @@ __global__ void row_norms_kernel(const float* x, uint32_t n, uint32_t d, float* 
 
 // D[q][j] = qn[q] + xn[x0 + j] - 2 * dot(Q[q], X[x0 + j]) for q < nq, j < cw.
 // 256 threads = 4 waves in 2 x 2; each wave owns a 64 x 64 part = 2 x 2 MFMA tiles of 32 x 32.
-__global__ __launch_bounds__(256) void dist_tile_kernel(const float* __restrict__ Q, const float* __restrict__ X,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void dist_tile_kernel(const float* __restrict__ Q, const float* __restrict__ X,
                                                         const float* __restrict__ qn, const float* __restrict__ xn,
                                                         uint32_t nq, uint32_t n, uint32_t d, uint32_t x0, uint32_t cw,
                                                         float* __restrict__ D)
