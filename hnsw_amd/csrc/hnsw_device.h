@@ -65,9 +65,11 @@ public:
     // scratch tier most queries of the last batch needed, and the ef / flags it was learnt at
     int hint_tier = 0, hint_ef = 0;
     uint32_t hint_flags = 0;
-    // factor on the first tier's table sizes, grown when a few queries of a batch overflowed, and the flags it was learnt at
+    // factor on the first tier's table sizes, grown when a few queries of a batch overflowed, and the ef / flags it
+    // was learnt at (another ef starts from the estimate again)
     float scratch_scale = 1.0f;
     uint32_t scale_flags = 0;
+    int scale_ef = 0;
 
     ~DeviceIndex();
     void release();

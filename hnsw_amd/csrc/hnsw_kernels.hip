@@ -1006,7 +1006,7 @@ void DeviceIndex::upload(const HostIndex& h, int dev)
     HIP_CHECK(hipDeviceSynchronize());
     version = h.version_;
     hint_tier = 0; hint_ef = 0; hint_flags = 0;
-    scratch_scale = 1.0f; scale_flags = 0;
+    scratch_scale = 1.0f; scale_flags = 0; scale_ef = 0;
 }
 
 void DeviceIndex::ensure_quantized(const HostIndex& h)
@@ -1073,13 +1073,17 @@ static SearchKernel pick_kernel(bool scalar, int wr, int rows)
 
 static ScratchTier tier_for(int ef, int tier, float scale)
 {
-    // Sized from measured search statistics (visited ~ 16-25 x ef on graphs of 10^4..10^6
-    // nodes, candidate heap <= ~6 x ef on integer data); a query that outgrows a tier is
-    // re-run on the next one.
-    const uint32_t want_visit = (uint32_t)((float)((uint32_t)ef * 28u + 192u) * scale);
+    // Sized from measured search statistics.  On a 10^6-node graph of degree 32 the largest visited count of
+    // 10^4 queries is close to 18.7 x ef + 470 for ef = 50..300 and the largest candidate heap close to
+    // 2.2 x ef + 120; small graphs and small ef stay below 28 x ef + 192 and 4 x ef.  The tables decide how many
+    // queries a CU holds, so they are cut close; a query that outgrows a tier is re-run on the next one.
+    const uint32_t e = (uint32_t)ef;
+    const uint32_t visit_est = std::min(e * 28u + 192u, (e * 39u) / 2u + 560u);
+    const uint32_t heap_est = std::min(e * 4u, (e * 12u) / 5u + 150u);
+    const uint32_t want_visit = (uint32_t)((float)visit_est * scale);
     // at most 7/8 full, with room for one more neighbour list of 64
     uint32_t hash_size = (((want_visit + 64u) * 8u + 6u) / 7u + 63u) & ~63u;
-    uint32_t cap_c = ((uint32_t)((float)((uint32_t)ef * 4u) * scale) + 63u) & ~63u;
+    uint32_t cap_c = std::max(((uint32_t)((float)heap_est * scale) + 31u) & ~31u, (e + 33u) & ~31u);   // W is sorted in C's space at the end
     hash_size <<= tier;
     cap_c <<= tier;
     return ScratchTier{hash_size, cap_c, want_visit << tier};
@@ -1145,7 +1149,7 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
     const int first_tier = (hint_tier > 0 && 4 * ef >= 3 * hint_ef && flags == hint_flags) ? hint_tier : 0;
     int crowded_tier = first_tier;
     bool grow_scale = false;
-    if (flags != scale_flags) { scratch_scale = 1.0f; scale_flags = flags; }
+    if (flags != scale_flags || ef != scale_ef) { scratch_scale = 1.0f; scale_flags = flags; scale_ef = ef; }
     for (int tier = first_tier;; tier++) {
         ScratchTier t = tier_for(ef, tier, scratch_scale);
         a.hash_size = t.hash_size; a.cap_c = t.cap_c; a.vis_rb = 0xFFFFFFFFu;

@@ -131,10 +131,11 @@ int hnsw_amd_aproximate_knn(hnsw_amd_index* h, const float* q, int k, int ef, ui
 int hnsw_amd_search_batch(hnsw_amd_index* h, const float* queries, uint32_t nq, int ef, uint32_t out_k,
                           uint32_t flags, uint32_t* out_ids, float* out_dist, uint32_t* out_count,
                           hnsw_amd_query_stats* stats);
-/* Same with every buffer already in device memory of the index's GPU; asynchronous on
- * `stream` (a hipStream_t, NULL = default stream).  *retried (host, may be NULL) receives
- * the number of queries that had to be re-run with a larger on-chip scratch; unless it is
- * NULL the call synchronises the stream to learn it. */
+/* Same with every buffer already in device memory of the index's GPU.  The kernel runs on
+ * `stream` (a hipStream_t, NULL = default stream); the call then waits for that stream to
+ * learn whether any query outgrew its on-chip scratch and re-runs those on larger tables,
+ * so every row of the outputs is final when it returns.  *retried (host, may be NULL)
+ * receives the number of queries that were re-run. */
 int hnsw_amd_search_batch_device(hnsw_amd_index* h, const float* d_queries, uint32_t nq, int ef, uint32_t out_k,
                                  uint32_t flags, uint32_t* d_out_ids, float* d_out_dist, uint32_t* d_out_count,
                                  hnsw_amd_query_stats* d_stats, void* stream, uint32_t* retried);

@@ -15,7 +15,7 @@ from hnsw_amd.flatgraph import FlatGraph  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=1_000_000)
 ap.add_argument("--nq", type=int, default=10_000)
-ap.add_argument("--ef", type=int, default=50)
+ap.add_argument("--ef", default="50", help="one ef or a comma separated list")
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--threads", type=int, default=16)
 ap.add_argument("--cache", default="")
@@ -37,13 +37,15 @@ else:
     if a.cache:
         np.savez(a.cache, **h.export_flat().to_npz_dict())
 h.sync_device(0)
-for rep in range(a.reps):
+from hnsw_amd import capi  # noqa: E402
+for ef in [int(x) for x in a.ef.split(",")]:
+  print(f"ef={ef}", flush=True)
+  for rep in range(a.reps):
     t = time.time()
-    from hnsw_amd import capi
     h.flags = capi.DIST_SSE | (capi.KEYS_FLOAT if a.keys == "float" else capi.KEYS_INT32) | (capi.ROWS_U8 if a.rows == "u8" else 0)
-    ids, ds, cnt, st = h.search_batch(q, a.ef, out_k=10, stats=True)
+    ids, ds, cnt, st = h.search_batch(q, ef, out_k=10, stats=True)
     print(f"rep {rep}: host wall {1e3*(time.time()-t):.2f} ms", flush=True)
-print("n_dist/q", st["n_dist"].mean(), "expansions/q", st["n_expand"].mean())
-for f in ("max_c", "n_visited0", "n_expand", "n_dist"):
+  print("n_dist/q", st["n_dist"].mean(), "expansions/q", st["n_expand"].mean())
+  for f in ("max_c", "n_visited0", "n_expand", "n_dist"):
     v = st[f]
     print(f, "mean", v.mean(), "p50", np.percentile(v, 50), "p99", np.percentile(v, 99), "max", v.max())
