@@ -529,6 +529,7 @@ __device__ __forceinline__ void w_sorted_insert(uint32_t (&wd)[WR], uint32_t (&w
     }
 #pragma unroll
     for (int w = WR - 1; w >= 0; w--) {
+        if (WR > 1 && 64u * (uint32_t)(w + 1) <= pos) break;     // this register and the ones below hold entries before the gap only
         uint32_t sd = (uint32_t)__builtin_amdgcn_update_dpp((int)wd[w], (int)wd[w], 0x138, 0xF, 0xF, false);   // wave_shr:1
         uint32_t si = (uint32_t)__builtin_amdgcn_update_dpp((int)wi[w], (int)wi[w], 0x138, 0xF, 0xF, false);
         if (w > 0) {
@@ -838,10 +839,23 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
         }
         LDS_SYNC();
     }
-    for (uint32_t i = lane; i < nW; i += 64) {
+    // Only entries that can rank below out_k take part.  The register form wrote W in ascending order of
+    // distance, so those are the first `nsort`: the entries not farther than the out_k-th.
+    uint32_t nsort = nW;
+    if (WR > 0 && ROWS != 2 && a.out_k < nW) {
+        const uint32_t dk = w_entry_dist<(WR > 0 ? WR : 1)>(wd, a.out_k - 1);
+        nsort = 0;
+#pragma unroll
+        for (int w = 0; w < (WR > 0 ? WR : 1); w++) {
+            const uint32_t left = nW > 64u * w ? nW - 64u * w : 0u;
+            const unsigned long long valid = left >= 64u ? ~0ull : (1ull << left) - 1ull;
+            nsort += (uint32_t)__popcll(__ballot(wd[w] <= dk) & valid);
+        }
+    }
+    for (uint32_t i = lane; i < nsort; i += 64) {
         const uint2 me = W[i];
         uint32_t rank = 0;
-        for (uint32_t j = 0; j < nW; j++) {
+        for (uint32_t j = 0; j < nsort; j++) {
             const uint2 o = W[j];
             rank += (o.x < me.x || (o.x == me.x && o.y < me.y)) ? 1u : 0u;   // non-negative floats order as their bits
         }
