@@ -4,7 +4,7 @@ import csv, glob, json, os, shutil, sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "v4"
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 g = lambda *p: os.path.join(R, *p)
-shutil.copy(g("gpurun_out", "pmc_v5", "summary.json"), g("profiles", "r1_pmc_search_kernel_v2.json"))
+shutil.copy(g("gpurun_out", "pmc_v5", "summary.json"), g("profiles", f"r1_pmc_search_kernel_{tag}.json"))
 shutil.copy(g("gpurun_out", "pmc_v5", "summary.json"), g("profiles", "pmc_search_kernel_latest.json"))
 shutil.copy(g("gpurun_out", "bench_final_v2.json"), g("profiles", f"r1_bench_1m_{tag}.json"))
 shutil.copy(g("gpurun_out", "prof_v2", "bench_under_rocprof.json"), g("profiles", f"r1_bench_1m_{tag}_under_rocprof.json"))
