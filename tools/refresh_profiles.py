@@ -23,7 +23,7 @@ with open(g("profiles", f"r1_bench_1m_{tag}_search_kernel_dispatches.csv"), "w",
     for r in tr:
         w.writerow([r[k] for k in keys] + [int(r["End_Timestamp"]) - int(r["Start_Timestamp"])])
 d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in tr]
-print("search kernel dispatches", len(d), "last-10 average ns", sum(d[-10:]) / 10)
+print("search kernel dispatches", len(d), "median ns (the timed steps; the first ones are the ef sweep, the last ones the large batch)", sorted(d)[len(d) // 2])
 print("under rocprof:", json.load(open(g("profiles", f"r1_bench_1m_{tag}_under_rocprof.json")))["roofline"])
 print("pmc:", {k: v for k, v in json.load(open(g("profiles", "pmc_search_kernel_latest.json"))).items() if k != "counters"})
 c = json.load(open(g("profiles", "pmc_search_kernel_latest.json")))["counters"]
