@@ -1085,15 +1085,17 @@ static SearchKernel pick_kernel(bool scalar, int wr, int rows)
     return pick_wr<false, 0>(wr);
 }
 
+constexpr size_t kLdsPerCu = 163840;     // gfx950: 160 KB
+
 static ScratchTier tier_for(int ef, int tier, float scale)
 {
     // Sized from measured search statistics.  On a 10^6-node graph of degree 32 the largest visited count of
     // 10^4 queries is close to 18.7 x ef + 470 for ef = 50..300 and the largest candidate heap close to
-    // 2.2 x ef + 120; small graphs and small ef stay below 28 x ef + 192 and 4 x ef.  The tables decide how many
+    // 2.2 x ef + 120; small ef stays below 28 x ef + 192 visited nodes.  The tables decide how many
     // queries a CU holds, so they are cut close; a query that outgrows a tier is re-run on the next one.
     const uint32_t e = (uint32_t)ef;
     const uint32_t visit_est = std::min(e * 28u + 192u, (e * 39u) / 2u + 560u);
-    const uint32_t heap_est = std::min(e * 4u, (e * 12u) / 5u + 150u);
+    const uint32_t heap_est = (e * 12u) / 5u + 150u;      // (the overflow test adds a whole neighbour list to the heap's size)
     const uint32_t want_visit = (uint32_t)((float)visit_est * scale);
     // at most 7/8 full, with room for one more neighbour list of 64
     uint32_t hash_size = (((want_visit + 64u) * 8u + 6u) / 7u + 63u) & ~63u;
@@ -1185,11 +1187,21 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
                     HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ32, reinterpret_cast<const void*>(kern), 64, lds));
                     HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ16, reinterpret_cast<const void*>(kern), 64, lds16));
                 } else {
-                    occ32 = (int)(163840 / lds); occ16 = (int)(163840 / lds16);
+                    occ32 = (int)(kLdsPerCu / lds); occ16 = (int)(kLdsPerCu / lds16);
                 }
                 // (beyond 16 queries per CU the cheaper 32-bit probe wins: measured on the byte-row kernel, 16 -> 20)
                 if (occ16 > occ32 && occ32 < 16) { a = b; lds = lds16; }
             }
+        }
+        // A CU runs at most 16 of these one-wave workgroups at a time, so a query may use a sixteenth of the CU's
+        // LDS at no cost in residency: what the estimate leaves of it goes to the tables (a quarter to the heap),
+        // which spares the occasional far-reaching query of a small-ef batch its re-run.
+        if (a.vis_rb == 0xFFFFFFFFu && lds < kLdsPerCu / 16) {
+            const uint32_t slack = (uint32_t)(kLdsPerCu / 16 - lds);
+            const uint32_t more_c = (slack / 4u / 8u) & ~31u;
+            a.cap_c += more_c;
+            a.hash_size += ((slack - more_c * 8u) / 4u) & ~63u;
+            lds = search_lds_bytes(a, std_heap);
         }
         if (lds > (size_t)max_lds) {
             throw std::length_error("search: " + std::to_string(a.nq_launch) +
