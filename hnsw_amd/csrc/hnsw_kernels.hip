@@ -94,16 +94,30 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t x)
 }
 
 
+// push in two halves, so that independent work can be placed between the LDS read and its use
 template <class Ord>
-__device__ __forceinline__ void heap_push_wave(uint2* a, uint32_t n /* size including the new element */, uint2 v, int lane)
+__device__ __forceinline__ uint2 heap_push_read(const uint2* a, uint32_t n /* size including the new element */, int lane)
+{
+    // every lane reads (the lanes past the chain of ancestors read some valid entry and are masked out of the
+    // ballot): no divergent region around the load
+    const uint32_t anc = n >> ((lane + 1) & 31);
+    return a[(anc > 0u ? anc : 1u) - 1u];
+}
+
+template <class Ord>
+__device__ __forceinline__ void heap_push_finish(uint2* a, uint32_t n, uint2 v, uint2 x /* from heap_push_read */, int lane)
 {
     const uint32_t depth = 31u - (uint32_t)__clz((int)n);        // levels above index n-1
-    uint2 x = make_uint2(0, 0);
-    if ((uint32_t)lane < depth) x = a[(n >> (lane + 1)) - 1];
-    const unsigned long long m = __ballot((uint32_t)lane < depth && Ord::before(x, v));
+    const unsigned long long m = __ballot(Ord::before(x, v)) & ((1ull << depth) - 1ull);
     const uint32_t t = (uint32_t)__builtin_ctzll(~m);            // ancestors that move down
     // lanes below t hand their ancestor down one level, lane t drops the new element into the gap
     if ((uint32_t)lane <= t) a[(n >> lane) - 1] = (uint32_t)lane < t ? x : v;
+}
+
+template <class Ord>
+__device__ __forceinline__ void heap_push_wave(uint2* a, uint32_t n /* size including the new element */, uint2 v, int lane)
+{
+    heap_push_finish<Ord>(a, n, v, heap_push_read<Ord>(a, n, lane), lane);
 }
 
 // Returns the new root (valid when n > 1).
@@ -147,10 +161,10 @@ __device__ __forceinline__ uint2 heap_pop_wave(uint2* a, uint32_t n /* size befo
     const uint32_t cur = p - 1;                                              // where the hole ends up
     // lane k owns step k of the path: the element at my_from moves up to my_to
     const uint32_t sh = d - (uint32_t)lane;                                  // meaningful for lane < d
-    const uint32_t my_to = (p >> (sh & 31u)) - 1, my_from = (p >> ((sh - 1) & 31u)) - 1;
-    uint2 x = make_uint2(0, 0);
-    if ((uint32_t)lane < d) x = a[my_from];
-    const unsigned long long cm = __ballot((uint32_t)lane < d && Ord::before(x, v));
+    const uint32_t my_to = (p >> (sh & 31u)) - 1;
+    const uint32_t from1 = p >> ((sh - 1) & 31u);          // 1-based; lanes past the path get some index <= p
+    const uint2 x = a[(from1 > 0u ? from1 : 1u) - 1u];     // read by every lane, the ballot is masked instead
+    const unsigned long long cm = __ballot(Ord::before(x, v)) & ((1ull << d) - 1ull);
     uint32_t s = 0;                                       // path elements (from the leaf up) that stay put
     if (d > 0) { s = (uint32_t)__builtin_clzll(~(cm << (64 - d))); if (s > d) s = d; }
     const uint32_t moved = d - s;
@@ -746,9 +760,10 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
                                 const uint32_t id = __builtin_amdgcn_readlane(my, j);
                                 const uint2 ce = make_uint2(__builtin_amdgcn_readlane(keym, j), id);
                                 nC++;
-                                heap_push_wave<COrder>(C, nC, ce, lane);
+                                const uint2 anc = heap_push_read<COrder>(C, nC, lane);      // in flight during the insert into W
                                 w_sorted_insert<(WR > 0 ? WR : 1)>(wd, wi, ef, db, id, lane);
                                 f = __uint_as_float(w_entry_dist<(WR > 0 ? WR : 1)>(wd, ef - 1));
+                                heap_push_finish<COrder>(C, nC, ce, anc, lane);
                                 LDS_SYNC();
                             }
                         }
