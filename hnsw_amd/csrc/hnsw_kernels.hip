@@ -132,11 +132,17 @@ __device__ __forceinline__ uint2 heap_pop_wave(uint2* a, uint32_t n /* size befo
     const uint32_t nint1 = nint < 256u ? nint : 256u;
     unsigned long long m0 = 0, m1 = 0, m2 = 0, m3 = 0;
     {
-        uint32_t i = lane;
-        m0 = __ballot(i < nint1 && Ord::before(a[2 * i + 2], a[2 * i + 1]));
-        if (nint1 > 64)  { i = lane + 64;  m1 = __ballot(i < nint1 && Ord::before(a[2 * i + 2], a[2 * i + 1])); }
-        if (nint1 > 128) { i = lane + 128; m2 = __ballot(i < nint1 && Ord::before(a[2 * i + 2], a[2 * i + 1])); }
-        if (nint1 > 192) { i = lane + 192; m3 = __ballot(i < nint1 && Ord::before(a[2 * i + 2], a[2 * i + 1])); }
+        // (every lane reads; nodes past nint1 read node 0's children and are masked out)
+        auto sibling_mask = [&](uint32_t base) -> unsigned long long {
+            const uint32_t i = base + (uint32_t)lane, ic = i < nint1 ? i : 0u;
+            const uint32_t left = nint1 - base;                  // > 0 where this is called
+            const unsigned long long valid = left >= 64u ? ~0ull : (1ull << left) - 1ull;
+            return __ballot(Ord::before(a[2 * ic + 2], a[2 * ic + 1])) & valid;
+        };
+        if (nint1 > 0)   m0 = sibling_mask(0);
+        if (nint1 > 64)  m1 = sibling_mask(64);
+        if (nint1 > 128) m2 = sibling_mask(128);
+        if (nint1 > 192) m3 = sibling_mask(192);
     }
     // Walk the hole down on the scalar unit, in 1-based indices: the children of p are 2p (left) and
     // 2p+1 (right), so the path is the bit string of the final index and step k of it is a shift.
