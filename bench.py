@@ -72,6 +72,10 @@ def main():
 
     from hnsw_amd import HNSW, capi, datagen, harness
 
+    # a rank that stops making progress prints every thread's stack and exits instead of hanging the job
+    import faulthandler
+    faulthandler.dump_traceback_later(int(os.environ.get("HNSW_AMD_BENCH_WATCHDOG", "1500")), exit=True)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -84,6 +88,9 @@ def main():
     local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # small tensors that only travel through collectives: on the GPU for RCCL, on the host for gloo (gloo's own
+    # handling of device tensors is not used)
+    cdev = dev if backend == "nccl" else torch.device("cpu")
     if world > 1:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -175,11 +182,12 @@ def main():
         dd = lambda ids: ((queries[samp][:, None, :].astype(np.float64) - base[ids].astype(np.float64)) ** 2).sum(-1)
         gt_info["cpu_double_check"] = bool(np.array_equal(dd(gsub), dd(cpu_gt)))    # same distances: equal up to exact ties
     if parts > 1:
-        all_d = [torch.empty_like(gd) for _ in range(world)]
-        all_i = [torch.empty_like(gi) for _ in range(world)]
-        dist.all_gather(all_d, gd)
-        dist.all_gather(all_i, gi)
-        cd, ci = torch.cat(all_d, 1), torch.cat(all_i, 1)
+        gd_c, gi_c = gd.to(cdev), gi.to(cdev)
+        all_d = [torch.empty_like(gd_c) for _ in range(world)]
+        all_i = [torch.empty_like(gi_c) for _ in range(world)]
+        dist.all_gather(all_d, gd_c)
+        dist.all_gather(all_i, gi_c)
+        cd, ci = torch.cat(all_d, 1).to(dev), torch.cat(all_i, 1).to(dev)
         _, sel = torch.topk(cd, k + 1, dim=1, largest=False)
         gi = torch.gather(ci, 1, sel)
     gt = gi.cpu().numpy()
@@ -253,7 +261,7 @@ def main():
     if world > 1 and parts == 1:
         # replicated: every rank picked its operating point on its own queries; they must agree, and the
         # reported recall is the mean over ranks
-        rt = torch.tensor([recall, float(ef), -float(ef)], dtype=torch.float64, device=dev)
+        rt = torch.tensor([recall, float(ef), -float(ef)], dtype=torch.float64, device=cdev)
         mx = rt.clone()
         dist.all_reduce(rt, op=dist.ReduceOp.SUM)
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -282,7 +290,7 @@ def main():
     elapsed = time.perf_counter() - t0
     step_ms_dev = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     ms_per_step = elapsed / args.steps * 1e3
@@ -479,7 +487,7 @@ def main():
             ef_r = e
             if args.ef or rec_r >= args.target_recall:
                 break
-        et = torch.tensor([float(ef_r)], dtype=torch.float64, device=dev)
+        et = torch.tensor([float(ef_r)], dtype=torch.float64, device=cdev)
         dist.all_reduce(et, op=dist.ReduceOp.MAX)       # every rank at the largest ef any rank needed
         ef_r = int(et.item())
         rstep(ef_r)
@@ -497,7 +505,7 @@ def main():
         dist.barrier()
         torch.cuda.synchronize()
         el = time.perf_counter() - t1
-        tt = torch.tensor([el, rec_r], dtype=torch.float64, device=dev)
+        tt = torch.tensor([el, rec_r], dtype=torch.float64, device=cdev)
         mx = tt.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         dist.all_reduce(tt, op=dist.ReduceOp.SUM)

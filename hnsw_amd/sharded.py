@@ -84,8 +84,15 @@ class ShardedHNSW:
             loc_i.copy_(li); loc_d.copy_(ld)
         if self.world == 1:
             return loc_i, loc_d
-        gathered = torch.empty((self.world, 2, nq, k), dtype=torch.int32, device=q_t.device)
-        dist.all_gather_into_tensor(gathered.view(-1), loc.view(-1), group=self.group)
+        if loc.is_cuda and dist.get_backend(self.group) != "nccl":
+            # a host-side backend (gloo: rehearsals of the multi-GPU path on one GPU): exchange host copies
+            loc_h = loc.cpu()
+            gathered_h = torch.empty((self.world, 2, nq, k), dtype=torch.int32)
+            dist.all_gather_into_tensor(gathered_h.view(-1), loc_h.view(-1), group=self.group)
+            gathered = gathered_h.to(q_t.device)
+        else:
+            gathered = torch.empty((self.world, 2, nq, k), dtype=torch.int32, device=q_t.device)
+            dist.all_gather_into_tensor(gathered.view(-1), loc.view(-1), group=self.group)
         if merge is not None:
             return merge(gathered[:, 0].view(torch.float32).contiguous(), gathered[:, 1].contiguous(), self.offsets, k)
         out_i = torch.empty((nq, k), dtype=torch.int32, device=q_t.device)
