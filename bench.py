@@ -72,9 +72,6 @@ def main():
 
     from hnsw_amd import HNSW, capi, datagen, harness
 
-    # a rank that stops making progress prints every thread's stack and exits instead of hanging the job
-    import faulthandler
-    faulthandler.dump_traceback_later(int(os.environ.get("HNSW_AMD_BENCH_WATCHDOG", "1500")), exit=True)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -134,6 +131,10 @@ def main():
             np.savez(cpath, **h.export_flat().to_npz_dict())
     build_s = time.time() - t0
     h.sync_device(local_rank)
+    # From here on (the host build above can take long and reports its own progress) a rank that stops making
+    # progress prints every thread's stack and exits instead of hanging the job.
+    import faulthandler
+    faulthandler.dump_traceback_later(int(os.environ.get("HNSW_AMD_BENCH_WATCHDOG", "1500")), exit=True)
 
     # ---- device buffers ----
     q_t = torch.from_numpy(queries).to(dev)
