@@ -1148,6 +1148,7 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
     if (device < 0) throw std::logic_error("search: index not on a device");
     if (nq == 0) return 0;
     if (ef < 1 || out_k < 1 || out_k > (uint32_t)ef) throw std::invalid_argument("search: need 1 <= out_k <= ef");
+    if (ef > (1 << 20)) throw std::length_error("search: ef beyond anything the on-chip scratch can hold");   // (and the size estimates stay in range)
     HIP_CHECK(hipSetDevice(device));
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
     if (fail_cap < nq + 1) {

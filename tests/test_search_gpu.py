@@ -115,9 +115,10 @@ def test_search_argument_errors():
     with pytest.raises(capi.HnswAmdError) as e:          # out_k > ef
         h.search_batch(q, 4, out_k=8)
     assert e.value.code == capi.E_ARG
-    with pytest.raises(capi.HnswAmdError) as e:          # an ef no on-chip scratch tier can hold
-        h.search_batch(q, 100000)
-    assert e.value.code == capi.E_SCRATCH
+    for ef in (100000, 2_000_000_000):                   # an ef no on-chip scratch tier can hold
+        with pytest.raises(capi.HnswAmdError) as e:
+            h.search_batch(q, ef, out_k=1)
+        assert e.value.code == capi.E_SCRATCH
     ids, dist, cnt = h.search_batch(q, 10)               # and the index still works
     assert (cnt == 10).all() and sorted(ids[0].tolist()) == list(range(10))
 
