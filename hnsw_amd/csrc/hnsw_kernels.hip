@@ -1116,7 +1116,8 @@ static ScratchTier tier_for(int ef, int tier, float scale)
     // queries a CU holds, so they are cut close; a query that outgrows a tier is re-run on the next one.
     const uint32_t e = (uint32_t)ef;
     const uint32_t visit_est = std::min(e * 28u + 192u, (e * 39u) / 2u + 560u);
-    const uint32_t heap_est = (e * 12u) / 5u + 150u;      // (the overflow test adds a whole neighbour list to the heap's size)
+    // (the overflow test adds a whole neighbour list to the heap's size; 4 x ef in steps of 64 is the smaller bound for small ef)
+    const uint32_t heap_est = std::min((e * 4u + 63u) & ~63u, (e * 12u) / 5u + 150u);
     const uint32_t want_visit = (uint32_t)((float)visit_est * scale);
     // at most 7/8 full, with room for one more neighbour list of 64
     uint32_t hash_size = (((want_visit + 64u) * 8u + 6u) / 7u + 63u) & ~63u;
@@ -1175,8 +1176,10 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
     a.out_ids = d_ids; a.out_dist = d_dist; a.out_count = d_count; a.stats = d_stats;
     const bool scalar = (flags & HNSW_AMD_DIST_SCALAR) != 0;
 
-    int max_lds = 0;
+    int max_lds = 0, num_cus = 0;
     HIP_CHECK(hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device));
+    HIP_CHECK(hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, device));
+    if (num_cus < 1) num_cus = 1;
 
     uint32_t retried = 0;
     uint32_t* cur = d_fail;
@@ -1196,11 +1199,17 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
         size_t lds = search_lds_bytes(a, std_heap);
         const int wr = std_heap ? 0 : (ef <= 64 ? 1 : (ef <= 128 ? 2 : 4));
         const SearchKernel kern = pick_kernel(scalar, wr, u8 ? 1 : (q8 ? 2 : 0));
+        // LDS a query may use without lowering residency: a CU runs at most 16 of these one-wave workgroups, and a
+        // batch of fewer than 16 queries per CU needs even fewer slots (bounded, so that clearing the tables stays cheap).
+        const uint32_t per_cu = std::min<uint32_t>(16u, (a.nq_launch + (uint32_t)num_cus - 1u) / (uint32_t)num_cus);
+        size_t budget = std::min<size_t>(kLdsPerCu / per_cu, 40960);
+        if (const char* cap = getenv("HNSW_AMD_LDS_BUDGET")) budget = std::min<size_t>(budget, (size_t)atol(cap));   // tests: bare estimates
         {
             // 16-bit visited slots where they let a CU hold more queries (what the kernel's registers and the
-            // LDS size allow together is asked from the runtime)
+            // LDS size allow together is asked from the runtime); HNSW_AMD_VISITED16 / HNSW_AMD_VISITED32 force a form
             uint32_t rb = 0, slots = 0;
-            if (!getenv("HNSW_AMD_VISITED32") && visited16_shape(g.n, t.want_visit, rb, slots)) {
+            const bool force16 = getenv("HNSW_AMD_VISITED16") != nullptr;
+            if (!getenv("HNSW_AMD_VISITED32") && (force16 || lds > budget) && visited16_shape(g.n, t.want_visit, rb, slots)) {
                 SearchArgs b = a;
                 b.hash_size = slots; b.vis_rb = rb;
                 const size_t lds16 = search_lds_bytes(b, std_heap);
@@ -1212,14 +1221,13 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
                     occ32 = (int)(kLdsPerCu / lds); occ16 = (int)(kLdsPerCu / lds16);
                 }
                 // (beyond 16 queries per CU the cheaper 32-bit probe wins: measured on the byte-row kernel, 16 -> 20)
-                if (occ16 > occ32 && occ32 < 16) { a = b; lds = lds16; }
+                if (force16 || (occ16 > occ32 && occ32 < 16)) { a = b; lds = lds16; }
             }
         }
-        // A CU runs at most 16 of these one-wave workgroups at a time, so a query may use a sixteenth of the CU's
-        // LDS at no cost in residency: what the estimate leaves of it goes to the tables (a quarter to the heap),
-        // which spares the occasional far-reaching query of a small-ef batch its re-run.
-        if (a.vis_rb == 0xFFFFFFFFu && lds < kLdsPerCu / 16) {
-            const uint32_t slack = (uint32_t)(kLdsPerCu / 16 - lds);
+        // What the estimate leaves of the budget goes to the tables (a quarter to the heap): a lower load makes the
+        // visited probes shorter, and the occasional far-reaching query is spared its re-run.
+        if (a.vis_rb == 0xFFFFFFFFu && lds < budget) {
+            const uint32_t slack = (uint32_t)(budget - lds);
             const uint32_t more_c = (slack / 4u / 8u) & ~31u;
             a.cap_c += more_c;
             a.hash_size += ((slack - more_c * 8u) / 4u) & ~63u;

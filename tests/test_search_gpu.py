@@ -92,16 +92,32 @@ def test_single_layer_and_tiny_graphs():
     assert (ids[:, 9:] == 0xFFFFFFFF).all() and np.isinf(dist[:, 9:]).all()
 
 
-def test_scratch_overflow_is_retried_transparently():
-    # a large ef on a small graph visits most nodes: tier 0 overflows for some queries
-    g = Golden("int_d128_n4000")
-    h = HNSW(*g.meta["ctor"])
-    h.import_flat(g.graph, g.base)
-    idx = oracle.OracleIndex(g.graph, g.base)
-    ids, dist, cnt = h.search_batch(g.queries, 200)
-    oi, od, oc = idx.search(g.queries, 200)
-    assert np.array_equal(cnt, oc)
-    assert_same_results(ids, dist, oi, od, what="ef=200")
+def test_scratch_overflow_is_retried_transparently(monkeypatch):
+    # Unit-norm vectors under the reference's int32 keys visit several times the nodes the first-tier estimate
+    # allows for (all keys are 0..3, the stop test never fires).  With the tables held to the bare estimate
+    # (HNSW_AMD_LDS_BUDGET: no spare LDS handed to them) queries overflow, are re-run on larger tiers, and the
+    # results are the oracle's all the same.
+    import torch
+    from hnsw_amd import datagen
+    monkeypatch.setenv("HNSW_AMD_LDS_BUDGET", "1")
+    base = datagen.make("glove", 30000, seed=4)
+    q = datagen.make("glove", 200, seed=4, stream=1)
+    h = HNSW(16, 16, 100)
+    h.init(base.shape[1], len(base))
+    h.insert_batch(base, threads=16)
+    h.sync_device(0)
+    ef, nq = 40, len(q)
+    q_t = torch.from_numpy(q).cuda()
+    ids_t = torch.empty((nq, ef), dtype=torch.int32, device="cuda")
+    dist_t = torch.empty((nq, ef), dtype=torch.float32, device="cuda")
+    cnt_t = torch.empty((nq,), dtype=torch.int32, device="cuda")
+    retried = h.search_batch_device(q_t.data_ptr(), nq, ef, ef, ids_t.data_ptr(), dist_t.data_ptr(), cnt_t.data_ptr(), 0,
+                                    torch.cuda.current_stream().cuda_stream, capi.DIST_SSE | capi.KEYS_INT32)
+    torch.cuda.synchronize()
+    assert retried > 0, "the bare first tier was expected to overflow on this data"
+    oi, od, oc = oracle.OracleIndex(h.export_flat(), base).search(q, ef)
+    assert np.array_equal(cnt_t.cpu().numpy().view(np.uint32), oc)
+    assert_same_results(ids_t.cpu().numpy().view(np.uint32), dist_t.cpu().numpy(), oi, od, what="overflow + re-run")
 
 
 def test_search_argument_errors():
@@ -140,8 +156,9 @@ def test_index_can_grow_between_searches():
 
 
 def test_both_forms_of_the_visited_set_give_the_same_search(monkeypatch):
-    """For larger ef the launcher switches the visited set to 16-bit slots in id-selected regions (half the
-    LDS); HNSW_AMD_VISITED32 keeps the 32-bit form.  Both are exact sets, so everything must be equal."""
+    """For larger ef and full batches the launcher switches the visited set to 16-bit slots in id-selected
+    regions (half the LDS); HNSW_AMD_VISITED16 / HNSW_AMD_VISITED32 force one form.  Both are exact sets, so
+    everything must be equal."""
     from hnsw_amd import datagen
     n = 70000                                   # more than 65535 ids: two regions
     base = datagen.make("sift", n, seed=9)
@@ -151,7 +168,9 @@ def test_both_forms_of_the_visited_set_give_the_same_search(monkeypatch):
     h.insert_batch(base, threads=16)
     for ef in (60, 100, 200, 256):
         monkeypatch.delenv("HNSW_AMD_VISITED32", raising=False)
+        monkeypatch.setenv("HNSW_AMD_VISITED16", "1")
         a = h.search_batch(q, ef, stats=True)
+        monkeypatch.delenv("HNSW_AMD_VISITED16", raising=False)
         monkeypatch.setenv("HNSW_AMD_VISITED32", "1")
         b = h.search_batch(q, ef, stats=True)
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
