@@ -202,33 +202,37 @@ __device__ __forceinline__ bool visited_insert32(uint32_t* hash, uint32_t size, 
 
 // Half-size form of the same exact set for large ef, where LDS decides how many queries a CU holds:
 // 2^rb regions selected by the low rb bits of the id, 16-bit slots holding the remaining bits
-// (the host checks that they fit below 0xFFFF = empty), linear probing inside the region.  A 16-bit
-// slot is claimed with a compare-and-swap on the 32-bit word around it.  A region can fill up
+// (the host checks that they fit below 0xFFFF = empty), linear probing inside the region.
+// No atomic is needed: the workgroup is one wavefront whose lanes run the loop in lockstep, so all
+// reads of an iteration see the table before any of that iteration's writes.  A lane that finds its
+// slot empty writes its tag (a 2-byte LDS store) and looks again in the next iteration: if several
+// lanes wrote different tags to one slot, one of them survives, its lane sees its own tag and is
+// done, the others see a foreign tag and probe on.  (Ids within one neighbour list are distinct, so
+// a tag read back as one's own after writing was put there by this lane.)  A region can fill up
 // while the table as a whole has room: that is reported through `overflow` (the query is then
 // re-run with larger tables, like any other scratch overflow).
 __device__ __forceinline__ bool visited_insert16(uint32_t* hash, uint32_t rb, uint32_t per_region, uint32_t id, bool& overflow)
 {
+    uint16_t* h16 = reinterpret_cast<uint16_t*>(hash);
     const uint32_t tag = id >> rb;
     const uint32_t first = (id & ((1u << rb) - 1u)) * per_region;
+    const uint32_t last = first + per_region;
     uint32_t slot = first + __umulhi(tag * 0x9E3779B1u, per_region);
-    uint32_t probes = 0;
-    bool fresh = false, done = false;
+    uint32_t probes = 0, wrote_at = 0xFFFFFFFFu;      // the slot this lane last wrote its tag to
+    bool hit;
     do {
-        const uint32_t sh = (slot & 1u) * 16u;
-        const uint32_t old = __hip_atomic_load(&hash[slot >> 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const uint32_t half = (old >> sh) & 0xFFFFu;
-        if (half == tag) {
-            done = true;
-        } else if (half == 0xFFFFu) {
-            const uint32_t want = (old & ~(0xFFFFu << sh)) | (tag << sh);
-            if (atomicCAS(&hash[slot >> 1], old, want) == old) { fresh = true; done = true; }
-            // else: the word changed under us, look at the slot again
-        } else {
-            slot = slot + 1 == first + per_region ? first : slot + 1;
-            if (++probes >= per_region) { overflow = true; done = true; }
-        }
-    } while (!done);
-    return fresh;
+        const uint32_t half = __hip_atomic_load(&h16[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        hit = half == tag;
+        const bool empty = half == 0xFFFFu;
+        if (empty) __hip_atomic_store(&h16[slot], (uint16_t)tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        wrote_at = empty ? slot : wrote_at;
+        const bool advance = !hit && !empty;
+        const uint32_t next = slot + 1 == last ? first : slot + 1;
+        probes += advance ? 1u : 0u;
+        slot = advance ? next : slot;
+    } while (!hit && probes < per_region);
+    overflow = overflow || !hit;
+    return hit && wrote_at == slot;                   // (the slot does not move on a hit)
 }
 
 // vis_rb == 0xFFFFFFFF: 32-bit slots; otherwise the region form with that many region bits.
