@@ -215,24 +215,30 @@ __device__ __forceinline__ bool visited_insert16(uint32_t* hash, uint32_t rb, ui
 {
     uint16_t* h16 = reinterpret_cast<uint16_t*>(hash);
     const uint32_t tag = id >> rb;
-    const uint32_t first = (id & ((1u << rb) - 1u)) * per_region;
-    const uint32_t last = first + per_region;
-    uint32_t slot = first + __umulhi(tag * 0x9E3779B1u, per_region);
+    // the region's slots are probed two at a time (one 32-bit word; regions hold an even number of slots)
+    const uint32_t pairs = per_region >> 1;
+    const uint32_t first = (id & ((1u << rb) - 1u)) * pairs;      // in words
+    const uint32_t last = first + pairs;
+    uint32_t word = first + __umulhi(tag * 0x9E3779B1u, pairs);
     uint32_t probes = 0, wrote_at = 0xFFFFFFFFu;      // the slot this lane last wrote its tag to
-    bool hit;
+    bool hit, fresh = false;
     do {
-        const uint32_t half = __hip_atomic_load(&h16[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        hit = half == tag;
-        const bool empty = half == 0xFFFFu;
-        if (empty) __hip_atomic_store(&h16[slot], (uint16_t)tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        wrote_at = empty ? slot : wrote_at;
+        const uint32_t w = __hip_atomic_load(&hash[word], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint32_t lo = w & 0xFFFFu, hi = w >> 16;
+        const bool hit_lo = lo == tag, hit_hi = hi == tag;
+        hit = hit_lo || hit_hi;
+        fresh = hit && wrote_at == 2u * word + (hit_lo ? 0u : 1u);
+        const bool empty_lo = lo == 0xFFFFu, empty = empty_lo || hi == 0xFFFFu;
+        const uint32_t target = 2u * word + (empty_lo ? 0u : 1u);
+        if (!hit && empty) __hip_atomic_store(&h16[target], (uint16_t)tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        wrote_at = (!hit && empty) ? target : wrote_at;
         const bool advance = !hit && !empty;
-        const uint32_t next = slot + 1 == last ? first : slot + 1;
+        const uint32_t next = word + 1 == last ? first : word + 1;
         probes += advance ? 1u : 0u;
-        slot = advance ? next : slot;
-    } while (!hit && probes < per_region);
+        word = advance ? next : word;
+    } while (!hit && probes < pairs);
     overflow = overflow || !hit;
-    return hit && wrote_at == slot;                   // (the slot does not move on a hit)
+    return fresh;
 }
 
 // vis_rb == 0xFFFFFFFF: 32-bit slots; otherwise the region form with that many region bits.
