@@ -1209,7 +1209,8 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
         size_t lds = search_lds_bytes(a, std_heap);
         const int wr = std_heap ? 0 : (ef <= 64 ? 1 : (ef <= 128 ? 2 : 4));
         const SearchKernel kern = pick_kernel(scalar, wr, u8 ? 1 : (q8 ? 2 : 0));
-        // LDS a query may use without lowering residency: a CU runs at most 16 of these one-wave workgroups, and a
+        // LDS a query may use without lowering residency: the float-row kernels need 110-118 VGPRs, i.e. 4 waves per
+        // SIMD = 16 one-wave workgroups per CU (the byte-row kernels could run 24, measured no faster than 16), and a
         // batch of fewer than 16 queries per CU needs even fewer slots (bounded, so that clearing the tables stays cheap).
         const uint32_t per_cu = std::min<uint32_t>(16u, (a.nq_launch + (uint32_t)num_cus - 1u) / (uint32_t)num_cus);
         size_t budget = std::min<size_t>(kLdsPerCu / per_cu, 40960);
