@@ -19,7 +19,9 @@ for f in sorted(glob.glob(f"{root}/p*/**/*counter_collection.csv", recursive=Tru
             vals[r["Counter_Name"]] = vals.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
             dur = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
             lds = r["LDS_Block_Size"]; vg = r["VGPR_Count"]
-out = {"counters": {k: int(v) for k, v in sorted(vals.items())}, "kernel_ns_under_pmc": dur, "lds_block": lds, "vgpr": vg}
+out = {"counters": {k: int(v) for k, v in sorted(vals.items())}, "kernel_ns_under_pmc": dur, "lds_block": lds,
+       # rocprofv3 reports half of what a wave64 kernel allocates: 56 here = 112 allocated (the code object says 110)
+       "vgpr_count_rocprof": vg}
 if "FETCH_SIZE" in vals:
     # FETCH_SIZE is in KiB and counts 64 B per 128-B request on gfx950 for wide reads: x2
     out["hbm_read_bytes_raw"] = int(vals["FETCH_SIZE"] * 1024)
