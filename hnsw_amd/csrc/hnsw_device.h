@@ -27,13 +27,6 @@ struct DeviceGraph {
     const uint32_t* up_adj_order;  // U x degu
 };
 
-// On-chip scratch configuration of one launch ("tier"): sizes of the per-query LDS structures.
-struct ScratchTier {
-    uint32_t hash_size;   // visited set: slots of 4 bytes (a multiple of 64, any otherwise)
-    uint32_t cap_c;       // candidate heap capacity (8-byte entries)
-    uint32_t want_visit;  // visited ids the table is meant to hold
-};
-
 struct SearchArgs {
     DeviceGraph g;
     const float* queries;     // nq x d (unpadded rows)
@@ -42,13 +35,16 @@ struct SearchArgs {
     uint32_t ef, out_k, flags;
     uint32_t hash_size, cap_c, cap_w;
     uint32_t vis_rb;          // 0xFFFFFFFF: visited slots of 32 bits; else 16-bit slots in 2^vis_rb regions   // cap_w: ef+1 rounded up to even
+    uint32_t vis_chunks;      // 16-bit bucket form: 16-byte chunks (8 slots) per region; 0: a probing form
+    uint32_t ovf_size;        // bucket form: 32-bit slots of the overflow table behind the primary one
     uint32_t qpad;            // floats of the query copy in LDS (multiple of 64)
     uint32_t* out_ids;        // nq x out_k
     float* out_dist;          // nq x out_k
     uint32_t* out_count;      // nq or nullptr
     hnsw_amd_query_stats* stats;   // nq or nullptr
-    uint32_t* fail_count;     // device word: number of queries whose scratch overflowed in this launch
-    uint32_t* fail_list;      // their query indices
+    uint32_t* fail_count;     // device words: [0] number of queries whose scratch overflowed in this launch,
+                              // [1] largest visited set, [2] most room the candidate heap was asked for, among the queries that finished
+    uint32_t* fail_list;      // the overflowed queries' indices
 };
 
 size_t search_lds_bytes(const SearchArgs& a, bool w_in_lds);
@@ -62,14 +58,11 @@ public:
     uint32_t* d_fail = nullptr;       // [0] = count, [1..] list
     uint32_t fail_cap = 0;
     uint32_t* h_fail = nullptr;       // pinned host mirror of d_fail[0]
-    // scratch tier most queries of the last batch needed, and the ef / flags it was learnt at
-    int hint_tier = 0, hint_ef = 0;
-    uint32_t hint_flags = 0;
-    // factor on the first tier's table sizes, grown when a few queries of a batch overflowed, and the ef / flags it
-    // was learnt at (another ef starts from the estimate again)
-    float scratch_scale = 1.0f;
-    uint32_t scale_flags = 0;
-    int scale_ef = 0;
+    // largest visited set and candidate heap the queries of earlier batches reached, and the ef / flags they were
+    // observed at: later batches are sized from them
+    uint32_t learn_flags = 0;
+    int learn_ef = 0;
+    uint32_t learn_visit = 0, learn_c = 0;
 
     ~DeviceIndex();
     void release();

@@ -29,6 +29,8 @@
 
 #include "hnsw_device.h"
 
+constexpr uint32_t kFailHeader = 4;      // words before the list: [0] count, [1] largest visited set, [2] most room C was asked for in the launch
+
 namespace hnsw_amd {
 
 #define HIP_CHECK(expr)                                                                              \
@@ -241,11 +243,83 @@ __device__ __forceinline__ bool visited_insert16(uint32_t* hash, uint32_t rb, ui
     return fresh;
 }
 
-// vis_rb == 0xFFFFFFFF: 32-bit slots; otherwise the region form with that many region bits.
-__device__ __forceinline__ bool visited_insert(uint32_t* hash, uint32_t size, uint32_t vis_rb, uint32_t id, bool& overflow)
+// Bucket form of the 16-bit set, for tables that must run nearly full (an index of many millions of rows needs
+// so many regions for its ids to fit 16-bit tags that a region's share of the visited ids is small, and sizing
+// every region for its worst case would give the saving away): 2^rb regions selected by the low rb bits of the
+// id, each `8 * nchunk` 16-bit slots of which the last holds the region's fill count minus one (so that the
+// cleared value 0xFFFF means empty) and the others are filled front to back.  A lookup reads the whole region
+// (nchunk 16-byte LDS reads) and tests all tags at once with word arithmetic, so it costs the same however
+// full the region is.  An id whose region is full goes to a small 32-bit table of the other kind (`ovf`); with
+// regions sized a little above their expected share only a few per cent of the ids end up there.
+// Insertion follows the lock-step argument of visited_insert16: the lanes that did not find their tag write it to
+// the slot the count points at, write the count, and read both back; of several lanes that wrote to one
+// slot one finds its own tag there and is done, the others find a foreign tag and the advanced count and try the
+// next slot.  (A tag read back as one's own was put there by this lane: the ids of one neighbour list are
+// distinct, and slots at or past the count never hold a tag.)  `used_ovf` reports that the id was looked up in
+// (and, when fresh, added to) the overflow table.
+__device__ __forceinline__ bool visited_insert_bucket(uint32_t* hash, uint32_t rb, uint32_t nchunk, uint32_t* ovf, uint32_t ovf_size,
+                                                      uint32_t id, bool& used_ovf)
 {
-    if (vis_rb == 0xFFFFFFFFu) return visited_insert32(hash, size, id);
-    return visited_insert16(hash, vis_rb, size >> vis_rb, id, overflow);
+    const uint32_t tag = id >> rb;
+    const uint32_t region = id & ((1u << rb) - 1u);
+    const uint32_t S = nchunk * 8u;
+    uint16_t* h16 = reinterpret_cast<uint16_t*>(hash) + region * S;
+    const uint4* reg = reinterpret_cast<const uint4*>(hash) + region * nchunk;
+    const uint32_t tt = tag * 0x00010001u;
+    // a half-word of x = w ^ tt is zero where the slot holds the tag; (x - 0x00010001) & ~x & 0x80008000 is
+    // non-zero exactly when some half-word of x is zero
+    uint32_t z = 0, last = 0;
+    LDS_SYNC();
+#pragma unroll
+    for (uint32_t c = 0; c < 4; c++)
+        if (c < nchunk) {
+            const uint4 v = reg[c];
+            uint32_t x;
+            x = v.x ^ tt; z |= (x - 0x00010001u) & ~x;
+            x = v.y ^ tt; z |= (x - 0x00010001u) & ~x;
+            x = v.z ^ tt; z |= (x - 0x00010001u) & ~x;
+            if (c + 1 == nchunk) {
+                last = v.w;
+                x = (v.w ^ tt) | 0x80000000u;        // the upper half is the count, not a tag
+            } else {
+                x = v.w ^ tt;
+            }
+            z |= (x - 0x00010001u) & ~x;
+        }
+    const bool hit = (z & 0x80008000u) != 0u;
+    uint32_t count = ((last >> 16) + 1u) & 0xFFFFu;
+    bool fresh = false, full = false, done = hit;
+    while (!done) {                         // (one exit) the lanes still inserting run in lock-step
+        const bool can = count < S - 1u;
+        if (can) { h16[count] = (uint16_t)tag; h16[S - 1u] = (uint16_t)count; }
+        LDS_SYNC();
+        const uint32_t back = h16[count], hdr = h16[S - 1u];
+        LDS_SYNC();
+        fresh = can && back == tag;
+        full = !can;
+        done = fresh || full;
+        count = (hdr + 1u) & 0xFFFFu;
+    }
+    used_ovf = full;
+    if (!full) return fresh;
+    return visited_insert32(ovf, ovf_size, id);
+}
+
+// The visited set of one query, in one of its three forms (chosen by the host per launch).
+struct VisitedSet {
+    uint32_t* hash;       // primary table
+    uint32_t size;        // its slots (32-bit form: words; 16-bit forms: half-words)
+    uint32_t rb;          // 0xFFFFFFFF: 32-bit slots, otherwise region bits of a 16-bit form
+    uint32_t nchunk;      // bucket form: 16-byte chunks per region; 0: probing form
+    uint32_t* ovf;        // bucket form: overflow table (32-bit slots)
+    uint32_t ovf_size;
+};
+
+__device__ __forceinline__ bool visited_insert(const VisitedSet& v, uint32_t id, bool& overflow, bool& used_ovf)
+{
+    if (v.rb == 0xFFFFFFFFu) return visited_insert32(v.hash, v.size, id);
+    if (v.nchunk != 0u) return visited_insert_bucket(v.hash, v.rb, v.nchunk, v.ovf, v.ovf_size, id, used_ovf);
+    return visited_insert16(v.hash, v.rb, v.size >> v.rb, id, overflow);
 }
 
 // Diagnostic build only (-DHNSW_DIAG): the counters struct is overwritten with cycle sums
@@ -613,9 +687,15 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
     uint2* C = W + (WR == 0 ? a.cap_w : 0u);
     uint32_t* hash = reinterpret_cast<uint32_t*>(C + a.cap_c);
     const uint32_t H = a.hash_size, vis_rb = a.vis_rb;
-    const uint32_t hash_words = vis_rb == 0xFFFFFFFFu ? H : H >> 1;
-    const uint32_t visit_limit = H - (H >> 3);       // keep the table at most 7/8 full
-    bool vis_ovf = false;
+    const uint32_t primary_words = vis_rb == 0xFFFFFFFFu ? H : H >> 1;
+    const uint32_t hash_words = primary_words + a.ovf_size;
+    const VisitedSet vs = {hash, H, vis_rb, a.vis_chunks, hash + primary_words, a.ovf_size};
+    // the probing forms are kept at most 7/8 full; the bucket form fills its regions completely and keeps its
+    // overflow table at most 7/8 full instead
+    const uint32_t visit_limit = a.vis_chunks ? 0xFFFFFFFFu : H - (H >> 3);
+    const uint32_t ovf_limit = a.vis_chunks ? a.ovf_size - (a.ovf_size >> 3) : 0xFFFFFFFFu;
+    uint32_t n_ovf = 0;
+    bool vis_ovf = false, used_ovf = false;
     const DistCtx dc = make_dist_ctx<SCALAR>(qs, a.g.d);
     const bool float_keys = (a.flags & HNSW_AMD_KEYS_FLOAT) != 0;
     const uint32_t ef = a.ef;
@@ -643,7 +723,8 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
     const int L = (int)a.g.nlayers - 1;
     uint32_t cur_slot = a.g.top_ep_slot, cur_id = a.g.top_ep_order;
     float cur_dist;
-    if (lane == 0) visited_insert(hash, H, vis_rb, cur_id, vis_ovf);
+    if (lane == 0) visited_insert(vs, cur_id, vis_ovf, used_ovf);
+    n_ovf += __ballot(lane == 0 && used_ovf) ? 1u : 0u;
     {
         uint32_t rid[RM::kSub]; bool act[RM::kSub]; float dj[RM::kSub];
 #pragma unroll
@@ -662,7 +743,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
         bool change = true;
         while (change && !fail) {
             change = false;
-            if (nvis + 64 > visit_limit) { fail = 1; break; }
+            if (nvis + 64 > visit_limit || n_ovf + 64 > ovf_limit) { fail = 1; break; }
             st.n_sweeps++;
             // The sweep covers the whole list of the node current at its start; the running best moves
             // only on a strict improvement, i.e. to the first minimum of the list.
@@ -671,8 +752,10 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
                 uint32_t my_order = kEmpty, my_slot = kEmpty;           // merged form
                 if (b0 + mrow < a.g.degu) { my_order = a.g.up_adj_order[rowi + b0 + mrow]; my_slot = a.g.up_adj_slot[rowi + b0 + mrow]; }
                 const bool live = my_order != kEmpty;
-                const bool fresh = live && visited_insert(hash, H, vis_rb, my_order, vis_ovf);
+                used_ovf = false;
+                const bool fresh = live && visited_insert(vs, my_order, vis_ovf, used_ovf);
                 if (__ballot(vis_ovf)) { fail = 1; break; }
+                n_ovf += (uint32_t)__popcll(__ballot(fresh && used_ovf));
                 const uint32_t m = (uint32_t)__popcll(__ballot(fresh));
                 st.sum_degu += (uint32_t)__popcll(__ballot(live));
                 st.n_dist += m; nvis += m;
@@ -703,7 +786,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
     DIAG_ADD(cy_up, t_begin, t_up_end);
 
     // ---- layer 0 beam search (src/hnsw.cpp:413-415, 725-787) ----
-    uint32_t nW = 0, nC = 0;
+    uint32_t nW = 0, nC = 0, c_need = 1;
     float f = 0.0f;
     uint32_t wd[WR > 0 ? WR : 1], wi[WR > 0 ? WR : 1];     // register form of W: distance bits, id
     if (!fail) {
@@ -713,8 +796,9 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
         if (lane == 0) {
             if (WR == 0) W[0] = make_uint2(__float_as_uint(cur_dist), cur_id);
             C[0] = make_uint2(float_keys ? __float_as_uint(cur_dist) : (uint32_t)trunc_key(cur_dist), cur_id);
-            visited_insert(hash, H, vis_rb, cur_id, vis_ovf);
+            visited_insert(vs, cur_id, vis_ovf, used_ovf);
         }
+        n_ovf = __ballot(lane == 0 && used_ovf) ? 1u : 0u;
 #pragma unroll
         for (int w = 0; w < (WR > 0 ? WR : 1); w++) { wd[w] = 0; wi[w] = 0; }
         if (WR > 0 && lane == 0) { wd[0] = __float_as_uint(cur_dist); wi[0] = cur_id; }
@@ -742,11 +826,13 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
             st.n_expand++;
             for (uint32_t b0 = 0;;) {
                 DIAG_STAMP(t1b);
-                if (nvis + 64 > visit_limit) { fail = 1; break; }
+                if (nvis + 64 > visit_limit || n_ovf + 64 > ovf_limit) { fail = 1; break; }
                 const bool live = my != kEmpty;
                 const uint32_t nlive = (uint32_t)__popcll(__ballot(live));
-                const bool fresh = live && visited_insert(hash, H, vis_rb, my, vis_ovf);
+                used_ovf = false;
+                const bool fresh = live && visited_insert(vs, my, vis_ovf, used_ovf);
                 if (__ballot(vis_ovf)) { fail = 1; break; }
+                n_ovf += (uint32_t)__popcll(__ballot(fresh && used_ovf));
                 const uint32_t m = (uint32_t)__popcll(__ballot(fresh));
                 st.sum_deg0 += nlive; st.n_dist += m; nvis += m;
                 LDS_SYNC();
@@ -764,7 +850,9 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
                     // `dist < f` against the f at the start of the expansion can only be admitted
                     // while W is not full; f never grows once W is full, so skipping the others is exact.
                     unsigned long long todo = __ballot(fresh && (dm < f || nW < ef));
-                    if (nC + (uint32_t)__popcll(todo) > a.cap_c) { fail = 2; break; }
+                    const uint32_t c_room = nC + (uint32_t)__popcll(todo);      // what the heap must have room for
+                    if (c_room > a.cap_c) { fail = 2; break; }
+                    c_need = c_room > c_need ? c_room : c_need;
                     const uint32_t keym = float_keys ? __float_as_uint(dm) : (uint32_t)trunc_key(dm);
                     if (WR > 0 && nW == ef) {
                         // W is full (the usual state): its size and the place of its largest entry are fixed
@@ -911,6 +999,13 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
     if (lane == 0) {
         if (a.out_count) a.out_count[qi] = nW;
         if (a.stats) a.stats[qi] = st;
+#ifndef HNSW_DIAG
+        // what this query needed of its scratch, for the sizing of later batches (the word is read rarely
+        // changed: most queries stay below the running maximum)
+        const uint32_t vmax = st.n_visited0 > st.n_visited_up ? st.n_visited0 : st.n_visited_up;
+        if (vmax > __hip_atomic_load(&a.fail_count[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&a.fail_count[1], vmax);
+        if (c_need > __hip_atomic_load(&a.fail_count[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&a.fail_count[2], c_need);
+#endif
     }
 }
 
@@ -963,7 +1058,7 @@ __global__ void store_rows_q8_kernel(const float* __restrict__ src, uint8_t* __r
 
 size_t search_lds_bytes(const SearchArgs& a, bool w_in_lds)
 {
-    size_t dwords = (size_t)a.qpad + (w_in_lds ? 2 * (size_t)a.cap_w : 0) + 2 * (size_t)a.cap_c + (a.vis_rb == 0xFFFFFFFFu ? (size_t)a.hash_size : (size_t)a.hash_size / 2);
+    size_t dwords = (size_t)a.qpad + (w_in_lds ? 2 * (size_t)a.cap_w : 0) + 2 * (size_t)a.cap_c + (a.vis_rb == 0xFFFFFFFFu ? (size_t)a.hash_size : (size_t)a.hash_size / 2) + (size_t)a.ovf_size;
     return dwords * 4;
 }
 
@@ -1050,8 +1145,7 @@ void DeviceIndex::upload(const HostIndex& h, int dev)
     g.up_adj_order = to_device(fg.up_adj_order, bufs_[5]);
     HIP_CHECK(hipDeviceSynchronize());
     version = h.version_;
-    hint_tier = 0; hint_ef = 0; hint_flags = 0;
-    scratch_scale = 1.0f; scale_flags = 0; scale_ef = 0;
+    learn_flags = 0; learn_ef = 0; learn_visit = 0; learn_c = 0;
 }
 
 void DeviceIndex::ensure_quantized(const HostIndex& h)
@@ -1118,31 +1212,24 @@ static SearchKernel pick_kernel(bool scalar, int wr, int rows)
 
 constexpr size_t kLdsPerCu = 163840;     // gfx950: 160 KB
 
-static ScratchTier tier_for(int ef, int tier, float scale)
-{
-    // Sized from measured search statistics.  On a 10^6-node graph of degree 32 the largest visited count of
-    // 10^4 queries is close to 18.7 x ef + 470 for ef = 50..300 and the largest candidate heap close to
-    // 2.2 x ef + 120; small ef stays below 28 x ef + 192 visited nodes.  The tables decide how many
-    // queries a CU holds, so they are cut close; a query that outgrows a tier is re-run on the next one.
-    const uint32_t e = (uint32_t)ef;
-    const uint32_t visit_est = std::min(e * 28u + 192u, (e * 39u) / 2u + 560u);
-    // (the overflow test adds a whole neighbour list to the heap's size; 4 x ef in steps of 64 is the smaller bound for small ef)
-    const uint32_t heap_est = std::min((e * 4u + 63u) & ~63u, (e * 12u) / 5u + 150u);
-    const uint32_t want_visit = (uint32_t)((float)visit_est * scale);
-    // at most 7/8 full, with room for one more neighbour list of 64
-    uint32_t hash_size = (((want_visit + 64u) * 8u + 6u) / 7u + 63u) & ~63u;
-    uint32_t cap_c = std::max(((uint32_t)((float)heap_est * scale) + 31u) & ~31u, (e + 33u) & ~31u);   // W is sorted in C's space at the end
-    hash_size <<= tier;
-    cap_c <<= tier;
-    return ScratchTier{hash_size, cap_c, want_visit << tier};
-}
+// First-batch estimates of what a search at `ef` needs, before anything was observed on this index.  On a
+// 10^6-node graph of degree 32 the largest visited count of 10^4 queries is close to 18.7 x ef + 470 for
+// ef = 50..300 and the largest candidate heap close to 2.2 x ef + 120; small ef stays below 28 x ef + 192
+// visited nodes.  Every launch reports the largest visited count and heap size its queries reached, and later
+// batches are sized from those (DeviceIndex::learn_*), so these figures only decide how the first batch starts.
+static uint32_t visit_estimate(int ef) { const uint32_t e = (uint32_t)ef; return std::min(e * 28u + 192u, (e * 39u) / 2u + 560u); }
+// (the overflow test adds a whole neighbour list to the heap's size; 4 x ef in steps of 64 is the smaller bound for small ef)
+static uint32_t heap_estimate(int ef) { const uint32_t e = (uint32_t)ef; return std::min((e * 4u + 63u) & ~63u, (e * 12u) / 5u + 150u); }
 
-// The half-size (16-bit slot) form of the visited table for `want_visit` ids below n, if the ids fit:
+// 32-bit probing table for `want_visit` ids: at most 7/8 full, with room for one more neighbour list of 64
+static uint32_t hash32_slots(uint32_t want_visit) { return (((want_visit + 64u) * 8u + 6u) / 7u + 63u) & ~63u; }
+
+// The half-size (16-bit slot) probing form of the visited table for `want_visit` ids below n, if the ids fit:
 // region bits and total slots (regions x an even number of slots each).  Regions are sized for their
 // expected share plus four standard deviations; a region that overflows anyway re-runs the query.
-static bool visited16_shape(uint32_t n, uint32_t want_visit, uint32_t& rb, uint32_t& slots)
+static bool visited16_shape(uint32_t n, uint32_t want_visit, uint32_t rb_min, uint32_t& rb, uint32_t& slots)
 {
-    rb = 0;
+    rb = rb_min;
     while (rb < 12 && ((n - 1u) >> rb) >= 0xFFFFu) rb++;
     if (((n - 1u) >> rb) >= 0xFFFFu) return false;
     const float share = (float)(want_visit + 64u) / (float)(1u << rb);
@@ -1151,6 +1238,38 @@ static bool visited16_shape(uint32_t n, uint32_t want_visit, uint32_t& rb, uint3
     if (per < 96u) return false;             // too small for the law of large numbers to help
     slots = per << rb;
     return true;
+}
+
+// The bucket form for `want_visit` ids below n: 2^rb regions of 8 * nchunk 16-bit slots plus an overflow table
+// of ovf_slots 32-bit slots (one slot of every region holds its fill count), the combination with the fewest bytes.  A region receives a Poisson share of the
+// visited ids (the low id bits of the nodes a search meets are as good as random); what does not fit goes to
+// the overflow table, which is sized for the expected total plus four standard deviations plus one batch.
+static bool bucket_shape(uint32_t n, uint32_t want_visit, uint32_t rb_min, uint32_t& rb, uint32_t& nchunk, uint32_t& ovf_slots)
+{
+    uint32_t rb0 = rb_min;
+    while (rb0 < 16 && ((n - 1u) >> rb0) >= 0xFFFFu) rb0++;
+    if (((n - 1u) >> rb0) >= 0xFFFFu) return false;
+    size_t best = ~(size_t)0;
+    for (uint32_t r = rb0; r <= rb0 + 8 && r <= 14; r++) {
+        const double R = (double)(1u << r), lambda = (double)(want_visit + 64u) / R;
+        for (uint32_t c = 2; c <= 4; c++) {
+            const uint32_t S = 8 * c;
+            if (lambda > 1.2 * S) continue;
+            // first and second moment of (X - U)+ for X ~ Poisson(lambda), U = S - 1 usable slots (one holds the count)
+            const uint32_t U = S - 1u;
+            double pk = exp(-lambda), e1 = 0.0, e2 = 0.0;
+            for (uint32_t k = 1; k <= U + 96; k++) {
+                pk *= lambda / (double)k;
+                if (k > U) { const double x = (double)(k - U); e1 += x * pk; e2 += x * x * pk; }
+            }
+            const double total = R * e1, sd = sqrt(std::max(0.0, R * (e2 - e1 * e1)));
+            const uint32_t need = (uint32_t)(total + 4.0 * sd) + 64u;
+            const uint32_t ovf = std::max(128u, hash32_slots(need));
+            const size_t bytes = (size_t)(1u << r) * S * 2 + (size_t)ovf * 4;
+            if (bytes < best) { best = bytes; rb = r; nchunk = c; ovf_slots = ovf; }
+        }
+    }
+    return best != ~(size_t)0;
 }
 
 uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32_t out_k, uint32_t flags, uint32_t* d_ids,
@@ -1162,14 +1281,19 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
     if (ef > (1 << 20)) throw std::length_error("search: ef beyond anything the on-chip scratch can hold");   // (and the size estimates stay in range)
     HIP_CHECK(hipSetDevice(device));
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
-    if (fail_cap < nq + 1) {
+    // the two overflow lists (kFailHeader words of header, then query indices): a retry launch reads one and
+    // appends to the other
+    uint32_t* list_a = nullptr;
+    uint32_t* list_b = nullptr;
+    if (fail_cap < nq + kFailHeader) {
         if (d_fail) HIP_CHECK(hipFree(d_fail));
         d_fail = nullptr;
-        HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_fail), ((size_t)nq + 1) * 4 * 2));
-        fail_cap = nq + 1;
-        if (!h_fail) HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_fail), 64, hipHostMallocDefault));
+        HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_fail), ((size_t)nq + kFailHeader) * 4 * 2));
+        fail_cap = nq + kFailHeader;
     }
-    uint32_t* d_fail_alt = d_fail + fail_cap;   // second list: a retry launch reads one and appends to the other
+    if (!h_fail) HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_fail), 64, hipHostMallocDefault));
+    list_a = d_fail;
+    list_b = d_fail + fail_cap;
 
     SearchArgs a{};
     a.g = g; a.queries = d_queries; a.qmap = nullptr; a.nq_launch = nq;
@@ -1191,19 +1315,34 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
     HIP_CHECK(hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, device));
     if (num_cus < 1) num_cus = 1;
 
+    // ---- what the queries of this batch are expected to need ----
+    // Sized from what earlier batches on this index were seen to need (the kernel reports the largest visited
+    // count and candidate heap of every launch): the same ef and flags with a twentieth of headroom, another ef by
+    // the ratio of observation to estimate at the ef it was made at (data on which searches visit several
+    // times the estimate, such as unit-norm vectors under the reference's int32 keys, do so at every ef).
+    if (flags != learn_flags) { learn_flags = flags; learn_ef = 0; learn_visit = 0; learn_c = 0; }
+    uint32_t want_visit0 = visit_estimate(ef), want_c0 = heap_estimate(ef);
+    if (learn_ef == ef) {
+        want_visit0 = learn_visit + learn_visit / 20u + 16u;
+        want_c0 = learn_c + learn_c / 32u + 4u;          // (learn_c is what the overflow test asked for, not the heap's size)
+    } else if (learn_ef != 0) {
+        const float rv = std::max(1.0f, 1.2f * (float)learn_visit / (float)visit_estimate(learn_ef));
+        const float rc = std::max(1.0f, 1.2f * (float)learn_c / (float)heap_estimate(learn_ef));
+        want_visit0 = (uint32_t)((float)want_visit0 * std::min(rv, 16.0f));
+        want_c0 = (uint32_t)((float)want_c0 * std::min(rc, 16.0f));
+    }
+    if (const char* e = getenv("HNSW_AMD_WANT_VISIT")) want_visit0 = (uint32_t)atoi(e);      // diagnostics: a fixed size
+    uint32_t rb_min = 0;
+    if (const char* e = getenv("HNSW_AMD_VIS_RB_MIN")) rb_min = (uint32_t)atoi(e);      // tests: the region count of a larger index
+
     uint32_t retried = 0;
-    uint32_t* cur = d_fail;
-    uint32_t* other = d_fail_alt;
-    // Start where most queries of the previous batch at a comparable ef ended up: on data where
-    // the search visits far more nodes than the tier-0 estimate (unit-norm vectors with the
-    // reference's int32 keys), running every query twice would double the work.
-    const int first_tier = (hint_tier > 0 && 4 * ef >= 3 * hint_ef && flags == hint_flags) ? hint_tier : 0;
-    int crowded_tier = first_tier;
-    bool grow_scale = false;
-    if (flags != scale_flags || ef != scale_ef) { scratch_scale = 1.0f; scale_flags = flags; scale_ef = ef; }
-    for (int tier = first_tier;; tier++) {
-        ScratchTier t = tier_for(ef, tier, scratch_scale);
-        a.hash_size = t.hash_size; a.cap_c = t.cap_c; a.vis_rb = 0xFFFFFFFFu;
+    uint32_t* cur = list_a;
+    uint32_t* other = list_b;
+    uint32_t seen_visit = 0, seen_c = 0;
+    for (int tier = 0;; tier++) {
+        const uint32_t want_visit = want_visit0 << tier;
+        a.hash_size = hash32_slots(want_visit); a.vis_rb = 0xFFFFFFFFu; a.vis_chunks = 0; a.ovf_size = 0;
+        a.cap_c = std::max(((want_c0 << tier) + 31u) & ~31u, ((uint32_t)ef + 33u) & ~31u);      // W is sorted in C's space at the end
         const bool std_heap = (flags & HNSW_AMD_W_STD_HEAP) != 0 || ef > 256;
         if (!std_heap && a.cap_w > a.cap_c) throw std::logic_error("search: W does not fit the space it borrows for the final sort");
         size_t lds = search_lds_bytes(a, std_heap);
@@ -1216,23 +1355,35 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
         size_t budget = std::min<size_t>(kLdsPerCu / per_cu, 40960);
         if (const char* cap = getenv("HNSW_AMD_LDS_BUDGET")) budget = std::min<size_t>(budget, (size_t)atol(cap));   // tests: bare estimates
         {
-            // 16-bit visited slots where they let a CU hold more queries (what the kernel's registers and the
-            // LDS size allow together is asked from the runtime); HNSW_AMD_VISITED16 / HNSW_AMD_VISITED32 force a form
-            uint32_t rb = 0, slots = 0;
-            const bool force16 = getenv("HNSW_AMD_VISITED16") != nullptr;
-            if (!getenv("HNSW_AMD_VISITED32") && (force16 || lds > budget) && visited16_shape(g.n, t.want_visit, rb, slots)) {
-                SearchArgs b = a;
-                b.hash_size = slots; b.vis_rb = rb;
-                const size_t lds16 = search_lds_bytes(b, std_heap);
-                int occ32 = 0, occ16 = 0;
-                if (lds <= 65536 && lds16 <= 65536) {
-                    HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ32, reinterpret_cast<const void*>(kern), 64, lds));
-                    HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ16, reinterpret_cast<const void*>(kern), 64, lds16));
-                } else {
-                    occ32 = (int)(kLdsPerCu / lds); occ16 = (int)(kLdsPerCu / lds16);
+            // 16-bit visited slots where they let a CU hold more queries: the probing form (large regions) or the
+            // bucket form (small regions read whole, nearly full, plus an overflow table), whichever needs less LDS.
+            // HNSW_AMD_VISITED32 / HNSW_AMD_VISITED16 / HNSW_AMD_VISITEDB force one form.
+            const bool force16 = getenv("HNSW_AMD_VISITED16") != nullptr, forceb = getenv("HNSW_AMD_VISITEDB") != nullptr;
+            if (!getenv("HNSW_AMD_VISITED32") && (force16 || forceb || lds > budget)) {
+                SearchArgs b16 = a, bb = a;
+                size_t lds16 = ~(size_t)0, ldsb = ~(size_t)0;
+                uint32_t rb = 0, slots = 0, nchunk = 0, ovf = 0;
+                if (!forceb && visited16_shape(g.n, want_visit, rb_min, rb, slots)) {
+                    b16.hash_size = slots; b16.vis_rb = rb;
+                    lds16 = search_lds_bytes(b16, std_heap);
                 }
-                // (beyond 16 queries per CU the cheaper 32-bit probe wins: measured on the byte-row kernel, 16 -> 20)
-                if (force16 || (occ16 > occ32 && occ32 < 16)) { a = b; lds = lds16; }
+                if (!force16 && bucket_shape(g.n, want_visit, rb_min, rb, nchunk, ovf)) {
+                    bb.hash_size = (8u * nchunk) << rb; bb.vis_rb = rb; bb.vis_chunks = nchunk; bb.ovf_size = ovf;
+                    ldsb = search_lds_bytes(bb, std_heap);
+                }
+                const bool use_b = ldsb < lds16;
+                const size_t ldsn = use_b ? ldsb : lds16;
+                if (ldsn != ~(size_t)0) {
+                    auto occupancy = [&](size_t bytes) {
+                        int occ = 0;
+                        if (bytes <= 65536) HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kern), 64, bytes));
+                        else occ = (int)(kLdsPerCu / bytes);
+                        return occ;
+                    };
+                    const int occ32 = occupancy(lds), occn = occupancy(ldsn);
+                    // (beyond 16 queries per CU the cheaper 32-bit probe wins: measured on the byte-row kernel, 16 -> 20)
+                    if (force16 || forceb || (occn > occ32 && occ32 < 16)) { a = use_b ? bb : b16; lds = ldsn; }
+                }
             }
         }
         // What the estimate leaves of the budget goes to the tables (a quarter to the heap): a lower load makes the
@@ -1248,16 +1399,20 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
             throw std::length_error("search: " + std::to_string(a.nq_launch) +
                                     " queries outgrew the largest on-chip scratch configuration (ef too large for LDS?)");
         }
-        a.fail_count = cur; a.fail_list = cur + 1;
-        HIP_CHECK(hipMemsetAsync(cur, 0, 4, stream));
+        a.fail_count = cur; a.fail_list = cur + kFailHeader;
+        HIP_CHECK(hipMemsetAsync(cur, 0, 4 * kFailHeader, stream));
         if (lds > 32768)
             HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         if (const char* pad = getenv("HNSW_AMD_LDS_PAD")) lds += (size_t)atoi(pad);      // occupancy experiments
         if (getenv("HNSW_AMD_VERBOSE")) {
             int nb = 0;
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), 64, lds);
-            fprintf(stderr, "[hnsw_amd] search launch: %u queries, ef=%d, tier %d (visited %u slots%s, C %u), LDS %zu B, resident queries per CU %d\n",
-                    a.nq_launch, ef, tier, a.hash_size, a.vis_rb == 0xFFFFFFFFu ? "" : " of 16 bits", a.cap_c, lds, nb);
+            char form[96];
+            if (a.vis_rb == 0xFFFFFFFFu) snprintf(form, sizeof form, "%u slots of 32 bits", a.hash_size);
+            else if (a.vis_chunks) snprintf(form, sizeof form, "%u regions x %u slots of 16 bits + %u overflow", 1u << a.vis_rb, 8u * a.vis_chunks, a.ovf_size);
+            else snprintf(form, sizeof form, "%u slots of 16 bits in %u regions", a.hash_size, 1u << a.vis_rb);
+            fprintf(stderr, "[hnsw_amd] search launch: %u queries, ef=%d, tier %d (visited: %s for %u ids, C %u), LDS %zu B, resident queries per CU %d\n",
+                    a.nq_launch, ef, tier, form, want_visit, a.cap_c, lds, nb);
         }
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         const bool timed = getenv("HNSW_AMD_VERBOSE") != nullptr && sync_and_retry;
@@ -1273,20 +1428,28 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
             (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
         }
         if (!sync_and_retry) return 0;
-        HIP_CHECK(hipMemcpyAsync(h_fail, cur, 4, hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipMemcpyAsync(h_fail, cur, 4 * kFailHeader, hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
-        uint32_t nfail = h_fail[0];
-        if (8 * (size_t)nfail >= nq) crowded_tier = tier + 1;      // an eighth of the batch or more needs the next tier
-        else if (nfail > 0 && tier == first_tier) grow_scale = true;   // a few stragglers: a slightly larger first tier next time
+        const uint32_t nfail = h_fail[0];
+        seen_visit = std::max(seen_visit, h_fail[1]);
+        seen_c = std::max(seen_c, h_fail[2]);
+        if (getenv("HNSW_AMD_VERBOSE"))
+            fprintf(stderr, "[hnsw_amd]   %u of %u queries outgrew their scratch; largest visited set %u, largest C %u\n", nfail, a.nq_launch, h_fail[1], h_fail[2]);
         if (nfail == 0) break;
         retried += nfail;
-        a.qmap = cur + 1; a.nq_launch = nfail;
+        a.qmap = cur + kFailHeader; a.nq_launch = nfail;
         std::swap(cur, other);
     }
-    if (crowded_tier != first_tier || first_tier == 0) { hint_tier = crowded_tier; hint_ef = ef; hint_flags = flags; }
-    // A re-run of a handful of queries costs a whole query latency, so the tables of the first tier grow
-    // by a quarter whenever that happened, until batches of this kind no longer overflow.
-    if (grow_scale && scratch_scale < 8.0f) scratch_scale *= 1.25f;
+    // remember what this batch needed (the maxima are those of the queries that finished, i.e. of all of them)
+    if (seen_visit == 0) {
+        // (a diagnostic build of the kernel reports nothing)
+    } else if (learn_ef == ef) {
+        // grows at once, shrinks slowly (one far-reaching query should not cost residency for ever)
+        learn_visit = std::max(seen_visit, (uint32_t)(((uint64_t)learn_visit * 15u + seen_visit) / 16u));
+        learn_c = std::max(seen_c, (uint32_t)(((uint64_t)learn_c * 15u + seen_c) / 16u));
+    } else if (nq >= 64 || learn_ef == 0) {
+        learn_ef = ef; learn_visit = seen_visit; learn_c = seen_c;
+    }
     return retried;
 }
 

@@ -155,10 +155,12 @@ def test_index_can_grow_between_searches():
     assert (ids[:, 0] == np.arange(300, 310)).all() or (dist[:, 0] == 0).all()
 
 
-def test_both_forms_of_the_visited_set_give_the_same_search(monkeypatch):
+def test_all_forms_of_the_visited_set_give_the_same_search(monkeypatch):
     """For larger ef and full batches the launcher switches the visited set to 16-bit slots in id-selected
-    regions (half the LDS); HNSW_AMD_VISITED16 / HNSW_AMD_VISITED32 force one form.  Both are exact sets, so
-    everything must be equal."""
+    regions (half the LDS), either probed linearly inside large regions or kept in small regions that are read
+    whole, with an overflow table; HNSW_AMD_VISITED32 / HNSW_AMD_VISITED16 / HNSW_AMD_VISITEDB force one form,
+    HNSW_AMD_VIS_RB_MIN the region count a larger index would have.  All are exact sets, so everything must be
+    equal, counters included."""
     from hnsw_amd import datagen
     n = 70000                                   # more than 65535 ids: two regions
     base = datagen.make("sift", n, seed=9)
@@ -166,13 +168,44 @@ def test_both_forms_of_the_visited_set_give_the_same_search(monkeypatch):
     h = HNSW(16, 16, 100)
     h.init(128, n)
     h.insert_batch(base, threads=16)
-    for ef in (60, 100, 200, 256):
-        monkeypatch.delenv("HNSW_AMD_VISITED32", raising=False)
-        monkeypatch.setenv("HNSW_AMD_VISITED16", "1")
-        a = h.search_batch(q, ef, stats=True)
-        monkeypatch.delenv("HNSW_AMD_VISITED16", raising=False)
-        monkeypatch.setenv("HNSW_AMD_VISITED32", "1")
-        b = h.search_batch(q, ef, stats=True)
-        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
-        for f in a[3].dtype.names:
-            assert np.array_equal(a[3][f], b[3][f]), f
+    envs = ("HNSW_AMD_VISITED32", "HNSW_AMD_VISITED16", "HNSW_AMD_VISITEDB")
+
+    def run(form, ef, rb_min=None):
+        for e in envs:
+            monkeypatch.delenv(e, raising=False)
+        monkeypatch.setenv(form, "1")
+        if rb_min is None:
+            monkeypatch.delenv("HNSW_AMD_VIS_RB_MIN", raising=False)
+        else:
+            monkeypatch.setenv("HNSW_AMD_VIS_RB_MIN", str(rb_min))
+        return h.search_batch(q, ef, stats=True)
+
+    for ef in (8, 60, 100, 200, 256, 300):
+        b = run("HNSW_AMD_VISITED32", ef)
+        for form, rb_min in (("HNSW_AMD_VISITED16", None), ("HNSW_AMD_VISITEDB", None), ("HNSW_AMD_VISITEDB", 8), ("HNSW_AMD_VISITEDB", 11)):
+            a = run(form, ef, rb_min)
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)), (form, rb_min, ef)
+            assert np.array_equal(a[2], b[2])
+            for f in a[3].dtype.names:
+                assert np.array_equal(a[3][f], b[3][f]), (form, rb_min, ef, f)
+
+
+def test_bucket_form_on_unit_norm_data_against_the_oracle(monkeypatch):
+    """The data the bucket form is for: unit-norm rows under int32 keys visit thousands of nodes at a small ef.
+    256 regions as for an index of 12.5 M rows; sizes learnt from the first batch are used by the second."""
+    from hnsw_amd import datagen
+    monkeypatch.setenv("HNSW_AMD_VISITEDB", "1")
+    monkeypatch.setenv("HNSW_AMD_VIS_RB_MIN", "8")
+    base = datagen.make("deep", 40000, seed=6)
+    q = datagen.make("deep", 400, seed=6, stream=1)
+    h = HNSW(16, 16, 100)
+    h.init(96, len(base))
+    h.insert_batch(base, threads=16)
+    idx = oracle.OracleIndex(h.export_flat(), base)
+    for ef in (30, 30, 10, 80):
+        ids, dist, cnt, st = h.search_batch(q, ef, stats=True)
+        oi, od, oc, ost = idx.search(q, ef, stats=True)
+        assert np.array_equal(cnt, oc)
+        assert_same_results(ids, dist, oi, od, what=f"deep ef={ef}")
+        for f in st.dtype.names:
+            assert np.array_equal(st[f], ost[f]), (ef, f)

@@ -21,18 +21,21 @@ ap.add_argument("--n", type=int, default=1_000_000)
 ap.add_argument("--nq", type=int, default=10_000)
 ap.add_argument("--ef", type=int, default=50)
 ap.add_argument("--threads", type=int, default=16)
+ap.add_argument("--kind", default="sift")
+ap.add_argument("--build-keys", default="int32", choices=["int32", "float"])
+ap.add_argument("--want-visit", type=int, default=0,
+                help="the diagnostic kernel reports no sizes, so the launcher cannot learn them: give the visited count to size for")
 a = ap.parse_args()
-base = datagen.make("sift", a.n, seed=1)
-q = datagen.make("sift", a.nq, seed=1, stream=1)
+base = datagen.make(a.kind, a.n, seed=1)
+q = datagen.make(a.kind, a.nq, seed=1, stream=1)
 h = HNSW(16, 16, 200)
-cache = "/tmp/g1m.npz"
-if a.n == 1_000_000 and os.path.exists(cache):
-    from hnsw_amd.flatgraph import FlatGraph
-    h.import_flat(FlatGraph.from_npz(np.load(cache)), base)
-else:
-    h.init(128, a.n)
-    t = time.time(); h.insert_batch(base, threads=a.threads); print(f"build {time.time()-t:.1f}s", flush=True)
+h.init(base.shape[1], a.n)
+if a.build_keys == "float":
+    h.set_build_float_keys(True)
+t = time.time(); h.insert_batch(base, threads=a.threads); print(f"build {time.time()-t:.1f}s", flush=True)
 h.sync_device(0)
+if a.want_visit:
+    os.environ["HNSW_AMD_WANT_VISIT"] = str(a.want_visit)
 for rep in range(2):
     t = time.time()
     ids, ds, cnt, st = h.search_batch(q, a.ef, out_k=10, stats=True)
