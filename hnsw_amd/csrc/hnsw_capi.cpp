@@ -138,6 +138,22 @@ int hnsw_amd_search_batch_device(hnsw_amd_index* h, const float* d_queries, uint
     });
 }
 
+int hnsw_amd_search_batch_device_noalloc(hnsw_amd_index* h, const float* d_queries, uint32_t nq, int ef, uint32_t out_k,
+                                         uint32_t flags, uint32_t* d_out_ids, float* d_out_dist, uint32_t* d_out_count,
+                                         hnsw_amd_query_stats* d_stats, void* stream, uint32_t* retried)
+{
+    return guarded([&] {
+        REQUIRE(h && d_queries && d_out_ids && d_out_dist, "search_batch_device_noalloc: NULL argument");
+        // everything that allocates (the HBM copy of the index, the quantised table) must have happened before
+        REQUIRE(h->dev.device == h->device && h->dev.version == h->host.version_,
+                "search_batch_device_noalloc: the index is not on the device (or changed since): call hnsw_amd_sync_device first");
+        REQUIRE(!(flags & HNSW_AMD_ROWS_Q8) || h->dev.g.vectors_q8 != nullptr,
+                "search_batch_device_noalloc: HNSW_AMD_ROWS_Q8 needs the quantised table, which an allocating search call builds on first use");
+        uint32_t r = h->dev.search(d_queries, nq, ef, out_k, flags, d_out_ids, d_out_dist, d_out_count, d_stats, stream, true, true);
+        if (retried) *retried = r;
+    });
+}
+
 int hnsw_amd_search_batch(hnsw_amd_index* h, const float* queries, uint32_t nq, int ef, uint32_t out_k, uint32_t flags,
                           uint32_t* out_ids, float* out_dist, uint32_t* out_count, hnsw_amd_query_stats* stats)
 {

@@ -71,8 +71,11 @@ public:
     void ensure_quantized(const HostIndex& h);
     // Runs the batch (device pointers), re-running overflowed queries on larger tiers.
     // Returns the number of re-run queries; throws on HIP errors / scratch exhaustion.
+    // no_alloc: the overflow lists live in the library's static device array instead of a buffer of this object
+    // (no allocation of any kind inside the call; the array is shared by all calls on the GPU).
     uint32_t search(const float* d_queries, uint32_t nq, int ef, uint32_t out_k, uint32_t flags, uint32_t* d_ids,
-                    float* d_dist, uint32_t* d_count, hnsw_amd_query_stats* d_stats, void* stream, bool sync_and_retry);
+                    float* d_dist, uint32_t* d_count, hnsw_amd_query_stats* d_stats, void* stream, bool sync_and_retry,
+                    bool no_alloc = false);
 
 private:
     void* bufs_[8] = {};

@@ -23,13 +23,21 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
 
 #include "hnsw_device.h"
 
+// Scratch of the search entry point that allocates nothing (hnsw_amd_search_batch_device_noalloc): the two
+// overflow lists of the retry protocol (a few header words, then query indices; twice), which the other entry
+// points keep in a buffer they allocate.  One copy per GPU, held until the process ends (512 KB).  In host
+// code this name is only a handle for hipGetSymbolAddress: the address a kernel can use is looked up once
+// per device (noalloc_scratch_for) and passed as an argument like any other buffer.
+constexpr uint32_t kNoAllocMaxQueries = 65535;
 constexpr uint32_t kFailHeader = 4;      // words before the list: [0] count, [1] largest visited set, [2] most room C was asked for in the launch
+static __device__ __align__(256) uint32_t scratch[2 * (kNoAllocMaxQueries + kFailHeader)];
 
 namespace hnsw_amd {
 
@@ -41,6 +49,25 @@ namespace hnsw_amd {
     } while (0)
 
 namespace {
+
+// Device address of `scratch` on each GPU (every GPU holds its own copy at its own address); filled when an
+// index is first uploaded to that GPU, with that GPU current.
+constexpr int kMaxDevices = 64;
+uint32_t* g_noalloc_scratch[kMaxDevices] = {};
+std::mutex g_noalloc_mutex;
+
+uint32_t* noalloc_scratch_for(int dev, bool lookup)
+{
+    if (dev < 0 || dev >= kMaxDevices) throw std::invalid_argument("search: device ordinal beyond the supported 64");
+    std::lock_guard<std::mutex> lock(g_noalloc_mutex);
+    if (!g_noalloc_scratch[dev] && lookup) {
+        uint32_t* ptr = nullptr;
+        HIP_CHECK(hipSetDevice(dev));
+        HIP_CHECK(hipGetSymbolAddress(reinterpret_cast<void**>(&ptr), HIP_SYMBOL(scratch)));
+        g_noalloc_scratch[dev] = ptr;
+    }
+    return g_noalloc_scratch[dev];
+}
 
 constexpr uint32_t kEmpty = 0xFFFFFFFFu;
 
@@ -1144,6 +1171,10 @@ void DeviceIndex::upload(const HostIndex& h, int dev)
     g.up_adj_slot = to_device(fg.up_adj_slot, bufs_[4]);
     g.up_adj_order = to_device(fg.up_adj_order, bufs_[5]);
     HIP_CHECK(hipDeviceSynchronize());
+    // set-up for the search calls: the pinned word the overflow count is read into, and this GPU's address of the
+    // static scratch array (so that a search call itself never has to allocate or look anything up)
+    if (!h_fail) HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_fail), 64, hipHostMallocDefault));
+    (void)noalloc_scratch_for(dev, true);
     version = h.version_;
     learn_flags = 0; learn_ef = 0; learn_visit = 0; learn_c = 0;
 }
@@ -1273,9 +1304,13 @@ static bool bucket_shape(uint32_t n, uint32_t want_visit, uint32_t rb_min, uint3
 }
 
 uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32_t out_k, uint32_t flags, uint32_t* d_ids,
-                             float* d_dist, uint32_t* d_count, hnsw_amd_query_stats* d_stats, void* stream_v, bool sync_and_retry)
+                             float* d_dist, uint32_t* d_count, hnsw_amd_query_stats* d_stats, void* stream_v, bool sync_and_retry,
+                             bool no_alloc)
 {
     if (device < 0) throw std::logic_error("search: index not on a device");
+    if (no_alloc && nq > kNoAllocMaxQueries)
+        throw std::invalid_argument("search (no-allocation entry point): at most " + std::to_string(kNoAllocMaxQueries) +
+                                    " queries per call, got " + std::to_string(nq));
     if (nq == 0) return 0;
     if (ef < 1 || out_k < 1 || out_k > (uint32_t)ef) throw std::invalid_argument("search: need 1 <= out_k <= ef");
     if (ef > (1 << 20)) throw std::length_error("search: ef beyond anything the on-chip scratch can hold");   // (and the size estimates stay in range)
@@ -1285,15 +1320,22 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
     // appends to the other
     uint32_t* list_a = nullptr;
     uint32_t* list_b = nullptr;
-    if (fail_cap < nq + kFailHeader) {
-        if (d_fail) HIP_CHECK(hipFree(d_fail));
-        d_fail = nullptr;
-        HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_fail), ((size_t)nq + kFailHeader) * 4 * 2));
-        fail_cap = nq + kFailHeader;
+    if (no_alloc) {
+        // this GPU's copy of the static scratch array, through the address looked up at upload (never the array's name)
+        list_a = noalloc_scratch_for(device, false);
+        if (!list_a || !h_fail) throw std::logic_error("search (no-allocation entry point): the index was not set up on this device");
+        list_b = list_a + (kNoAllocMaxQueries + kFailHeader);
+    } else {
+        if (fail_cap < nq + kFailHeader) {
+            if (d_fail) HIP_CHECK(hipFree(d_fail));
+            d_fail = nullptr;
+            HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_fail), ((size_t)nq + kFailHeader) * 4 * 2));
+            fail_cap = nq + kFailHeader;
+        }
+        if (!h_fail) HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_fail), 64, hipHostMallocDefault));
+        list_a = d_fail;
+        list_b = d_fail + fail_cap;
     }
-    if (!h_fail) HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_fail), 64, hipHostMallocDefault));
-    list_a = d_fail;
-    list_b = d_fail + fail_cap;
 
     SearchArgs a{};
     a.g = g; a.queries = d_queries; a.qmap = nullptr; a.nq_launch = nq;
@@ -1415,7 +1457,7 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
                     a.nq_launch, ef, tier, form, want_visit, a.cap_c, lds, nb);
         }
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
-        const bool timed = getenv("HNSW_AMD_VERBOSE") != nullptr && sync_and_retry;
+        const bool timed = getenv("HNSW_AMD_VERBOSE") != nullptr && sync_and_retry && !no_alloc;
         if (timed) { HIP_CHECK(hipEventCreate(&ev0)); HIP_CHECK(hipEventCreate(&ev1)); HIP_CHECK(hipEventRecord(ev0, stream)); }
         hipLaunchKernelGGL(kern, dim3(a.nq_launch), dim3(64), lds, stream, a);
         HIP_CHECK(hipGetLastError());

@@ -105,6 +105,15 @@ class HNSW:
                                                            d_count or None, d_stats or None, stream or None, C.byref(retried)))
         return retried.value
 
+    def search_batch_device_noalloc(self, d_queries: int, nq: int, ef: int, out_k: int, d_ids: int, d_dist: int, d_count: int = 0,
+                                    d_stats: int = 0, stream: int = 0, flags: int | None = None) -> int:
+        """search_batch_device through the entry point that allocates nothing (the index must be on its device already)."""
+        retried = C.c_uint32(0)
+        capi.check(capi.lib().hnsw_amd_search_batch_device_noalloc(self._h, d_queries, nq, ef, out_k,
+                                                                   self.flags if flags is None else flags, d_ids, d_dist,
+                                                                   d_count or None, d_stats or None, stream or None, C.byref(retried)))
+        return retried.value
+
     # -- flat graph exchange ---------------------------------------------------------------
     def import_flat(self, g: FlatGraph, vectors: np.ndarray) -> None:
         v = np.ascontiguousarray(vectors, dtype=np.float32)

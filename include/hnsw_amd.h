@@ -140,6 +140,19 @@ int hnsw_amd_search_batch_device(hnsw_amd_index* h, const float* d_queries, uint
                                  uint32_t flags, uint32_t* d_out_ids, float* d_out_dist, uint32_t* d_out_count,
                                  hnsw_amd_query_stats* d_stats, void* stream, uint32_t* retried);
 
+/* No counterpart in the reference.  hnsw_amd_search_batch_device for callers that cannot allocate device memory
+ * (tight serving loops, harnesses that forbid hipMalloc): same arguments, same results, but the call itself
+ * allocates nothing, neither on the device nor pinned host memory.  The lists of the retry protocol (queries that
+ * outgrew their on-chip scratch) live in a static device array of the library, 512 KB per GPU, held until the
+ * process ends.  Limits: nq <= 65535 per call (HNSW_AMD_E_ARG beyond); the index must already be on its device
+ * (hnsw_amd_sync_device after the last insert/load; HNSW_AMD_E_ARG otherwise), and with HNSW_AMD_ROWS_Q8 the
+ * quantised table must exist already.  All calls a process makes on one GPU share that array (whatever the index):
+ * calls that overlap in time on the same GPU race and must be serialised by the caller.  Like the entry point
+ * above it waits for `stream` before it returns. */
+int hnsw_amd_search_batch_device_noalloc(hnsw_amd_index* h, const float* d_queries, uint32_t nq, int ef, uint32_t out_k,
+                                         uint32_t flags, uint32_t* d_out_ids, float* d_out_dist, uint32_t* d_out_count,
+                                         hnsw_amd_query_stats* d_stats, void* stream, uint32_t* retried);
+
 /* HNSW::saveGraph / HNSW::loadGraph — src/hnsw.cpp:1178-1240, 1244-1311; same file format. */
 int hnsw_amd_save_graph(hnsw_amd_index* h, const char* filename);
 int hnsw_amd_load_graph(hnsw_amd_index* h, const char* filename);
