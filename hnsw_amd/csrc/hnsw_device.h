@@ -37,17 +37,27 @@ struct SearchArgs {
     uint32_t vis_rb;          // 0xFFFFFFFF: visited slots of 32 bits; else 16-bit slots in 2^vis_rb regions   // cap_w: ef+1 rounded up to even
     uint32_t vis_chunks;      // 16-bit bucket form: 16-byte chunks (8 slots) per region; 0: a probing form
     uint32_t ovf_size;        // bucket form: 32-bit slots of the overflow table behind the primary one
+    uint32_t vis_regions, vis_magic;   // bucket form: number of regions (any), floor(2^32 / regions)
+    uint32_t* spill_pool;     // bucket form: spill tables in device memory for queries that outgrow the overflow table
+    uint32_t spill_tables, spill_slots;   // how many, and 32-bit slots each (0 tables: such queries are re-run instead)
     uint32_t qpad;            // floats of the query copy in LDS (multiple of 64)
     uint32_t* out_ids;        // nq x out_k
     float* out_dist;          // nq x out_k
     uint32_t* out_count;      // nq or nullptr
     hnsw_amd_query_stats* stats;   // nq or nullptr
     uint32_t* fail_count;     // device words: [0] number of queries whose scratch overflowed in this launch,
-                              // [1] largest visited set, [2] most room the candidate heap was asked for, among the queries that finished
+                              // [1] largest visited set, [2] most room the candidate heap was asked for, among the queries
+                              // that finished, [3] spill tables handed out, [4] sum of the visited counts / 16 and [5] number of a sample of them
     uint32_t* fail_list;      // the overflowed queries' indices
 };
 
 size_t search_lds_bytes(const SearchArgs& a, bool w_in_lds);
+
+struct BucketShape {
+    uint32_t n = 0, want = 0, rb_min = 0;     // what it was computed for
+    uint32_t regions = 0, chunks = 0, ovf = 0;
+    bool ok = false;
+};
 
 class DeviceIndex {
 public:
@@ -57,12 +67,17 @@ public:
     // scratch for the retry protocol
     uint32_t* d_fail = nullptr;       // [0] = count, [1..] list
     uint32_t fail_cap = 0;
-    uint32_t* h_fail = nullptr;       // pinned host mirror of d_fail[0]
+    uint32_t* h_fail = nullptr;       // pinned host mirror of the list header
+    uint32_t* d_spill = nullptr;      // pool of spill tables (bucket form of the visited set), allocated on first need
     // largest visited set and candidate heap the queries of earlier batches reached, and the ef / flags they were
     // observed at: later batches are sized from them
     uint32_t learn_flags = 0;
     int learn_ef = 0;
     uint32_t learn_visit = 0, learn_c = 0;
+    uint32_t learn_mean = 0;          // mean visited count of those batches
+    // last shapes computed for the bucket form of the visited set (the search over shapes is not free): sized for
+    // the farthest-reaching query, and for the bulk of the queries
+    BucketShape shape_full, shape_bulk;
 
     ~DeviceIndex();
     void release();

@@ -36,7 +36,8 @@
 // code this name is only a handle for hipGetSymbolAddress: the address a kernel can use is looked up once
 // per device (noalloc_scratch_for) and passed as an argument like any other buffer.
 constexpr uint32_t kNoAllocMaxQueries = 65535;
-constexpr uint32_t kFailHeader = 4;      // words before the list: [0] count, [1] largest visited set, [2] most room C was asked for in the launch
+constexpr uint32_t kFailHeader = 8;      // words before the list: [0] count, [1] largest visited set, [2] most room C was asked for in the
+                                         // launch, [3] spill tables handed out, [4] sum of visited counts / 16 and [5] number of a sample (one in 32) of the queries that finished
 static __device__ __align__(256) uint32_t scratch[2 * (kNoAllocMaxQueries + kFailHeader)];
 
 namespace hnsw_amd {
@@ -278,17 +279,24 @@ __device__ __forceinline__ bool visited_insert16(uint32_t* hash, uint32_t rb, ui
 // (nchunk 16-byte LDS reads) and tests all tags at once with word arithmetic, so it costs the same however
 // full the region is.  An id whose region is full goes to a small 32-bit table of the other kind (`ovf`); with
 // regions sized a little above their expected share only a few per cent of the ids end up there.
+// `regions` is any number (region = id mod regions, tag = id div regions < 0xFFFF; `magic` =
+// floor(2^32 / regions) gives the quotient to within one).
+// Once the overflow table has reached its limit the query is given a table in device memory (`spill`, same
+// 32-bit form): from then on the overflow table is only read, and what it does not hold is looked up in and
+// added to the spill table.  Only the few queries that visit far more nodes than most get there, late in their
+// search, so the tables in LDS can be sized for the bulk of the queries instead of the worst one.
 // Insertion follows the lock-step argument of visited_insert16: the lanes that did not find their tag write it to
 // the slot the count points at, write the count, and read both back; of several lanes that wrote to one
 // slot one finds its own tag there and is done, the others find a foreign tag and the advanced count and try the
 // next slot.  (A tag read back as one's own was put there by this lane: the ids of one neighbour list are
 // distinct, and slots at or past the count never hold a tag.)  `used_ovf` reports that the id was looked up in
 // (and, when fresh, added to) the overflow table.
-__device__ __forceinline__ bool visited_insert_bucket(uint32_t* hash, uint32_t rb, uint32_t nchunk, uint32_t* ovf, uint32_t ovf_size,
-                                                      uint32_t id, bool& used_ovf)
+__device__ __forceinline__ bool visited_insert_bucket(uint32_t* hash, uint32_t regions, uint32_t magic, uint32_t nchunk, uint32_t* ovf,
+                                                      uint32_t ovf_size, uint32_t* spill, uint32_t spill_slots, uint32_t id, bool& used_ovf)
 {
-    const uint32_t tag = id >> rb;
-    const uint32_t region = id & ((1u << rb) - 1u);
+    uint32_t tag = __umulhi(id, magic);
+    uint32_t region = id - tag * regions;
+    if (region >= regions) { tag++; region -= regions; }
     const uint32_t S = nchunk * 8u;
     uint16_t* h16 = reinterpret_cast<uint16_t*>(hash) + region * S;
     const uint4* reg = reinterpret_cast<const uint4*>(hash) + region * nchunk;
@@ -329,23 +337,36 @@ __device__ __forceinline__ bool visited_insert_bucket(uint32_t* hash, uint32_t r
     }
     used_ovf = full;
     if (!full) return fresh;
-    return visited_insert32(ovf, ovf_size, id);
+    if (!spill) return visited_insert32(ovf, ovf_size, id);
+    // the overflow table is closed: look only
+    {
+        uint32_t slot = __umulhi(id * 0x9E3779B1u, ovf_size), old;
+        do {
+            old = ovf[slot];
+            slot = slot + 1 == ovf_size ? 0u : slot + 1;
+        } while (old != kEmpty && old != id);
+        if (old == id) return false;
+    }
+    return visited_insert32(spill, spill_slots, id);
 }
 
 // The visited set of one query, in one of its three forms (chosen by the host per launch).
 struct VisitedSet {
     uint32_t* hash;       // primary table
     uint32_t size;        // its slots (32-bit form: words; 16-bit forms: half-words)
-    uint32_t rb;          // 0xFFFFFFFF: 32-bit slots, otherwise region bits of a 16-bit form
-    uint32_t nchunk;      // bucket form: 16-byte chunks per region; 0: probing form
+    uint32_t rb;          // 0xFFFFFFFF: 32-bit slots, otherwise region bits of the 16-bit probing form
+    uint32_t nchunk;      // bucket form: 16-byte chunks per region; 0: a probing form
+    uint32_t regions, magic;   // bucket form: number of regions, floor(2^32 / regions)
     uint32_t* ovf;        // bucket form: overflow table (32-bit slots)
     uint32_t ovf_size;
+    uint32_t spill_slots; // bucket form: slots of a spill table in device memory
 };
 
-__device__ __forceinline__ bool visited_insert(const VisitedSet& v, uint32_t id, bool& overflow, bool& used_ovf)
+// `spill`: the query's spill table once it has one (bucket form only), else nullptr.
+__device__ __forceinline__ bool visited_insert(const VisitedSet& v, uint32_t* spill, uint32_t id, bool& overflow, bool& used_ovf)
 {
     if (v.rb == 0xFFFFFFFFu) return visited_insert32(v.hash, v.size, id);
-    if (v.nchunk != 0u) return visited_insert_bucket(v.hash, v.rb, v.nchunk, v.ovf, v.ovf_size, id, used_ovf);
+    if (v.nchunk != 0u) return visited_insert_bucket(v.hash, v.regions, v.magic, v.nchunk, v.ovf, v.ovf_size, spill, v.spill_slots, id, used_ovf);
     return visited_insert16(v.hash, v.rb, v.size >> v.rb, id, overflow);
 }
 
@@ -716,7 +737,10 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
     const uint32_t H = a.hash_size, vis_rb = a.vis_rb;
     const uint32_t primary_words = vis_rb == 0xFFFFFFFFu ? H : H >> 1;
     const uint32_t hash_words = primary_words + a.ovf_size;
-    const VisitedSet vs = {hash, H, vis_rb, a.vis_chunks, hash + primary_words, a.ovf_size};
+    const VisitedSet vs = {hash, H, vis_rb, a.vis_chunks, a.vis_regions, a.vis_magic, hash + primary_words, a.ovf_size, a.spill_slots};
+    uint32_t* spill = nullptr;           // this query's spill table, once it needed one (layer 0 only)
+    uint32_t n_spill = 0;
+    const uint32_t spill_limit = a.spill_slots - (a.spill_slots >> 3);
     // the probing forms are kept at most 7/8 full; the bucket form fills its regions completely and keeps its
     // overflow table at most 7/8 full instead
     const uint32_t visit_limit = a.vis_chunks ? 0xFFFFFFFFu : H - (H >> 3);
@@ -750,7 +774,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
     const int L = (int)a.g.nlayers - 1;
     uint32_t cur_slot = a.g.top_ep_slot, cur_id = a.g.top_ep_order;
     float cur_dist;
-    if (lane == 0) visited_insert(vs, cur_id, vis_ovf, used_ovf);
+    if (lane == 0) visited_insert(vs, nullptr, cur_id, vis_ovf, used_ovf);
     n_ovf += __ballot(lane == 0 && used_ovf) ? 1u : 0u;
     {
         uint32_t rid[RM::kSub]; bool act[RM::kSub]; float dj[RM::kSub];
@@ -780,7 +804,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
                 if (b0 + mrow < a.g.degu) { my_order = a.g.up_adj_order[rowi + b0 + mrow]; my_slot = a.g.up_adj_slot[rowi + b0 + mrow]; }
                 const bool live = my_order != kEmpty;
                 used_ovf = false;
-                const bool fresh = live && visited_insert(vs, my_order, vis_ovf, used_ovf);
+                const bool fresh = live && visited_insert(vs, nullptr, my_order, vis_ovf, used_ovf);
                 if (__ballot(vis_ovf)) { fail = 1; break; }
                 n_ovf += (uint32_t)__popcll(__ballot(fresh && used_ovf));
                 const uint32_t m = (uint32_t)__popcll(__ballot(fresh));
@@ -823,7 +847,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
         if (lane == 0) {
             if (WR == 0) W[0] = make_uint2(__float_as_uint(cur_dist), cur_id);
             C[0] = make_uint2(float_keys ? __float_as_uint(cur_dist) : (uint32_t)trunc_key(cur_dist), cur_id);
-            visited_insert(vs, cur_id, vis_ovf, used_ovf);
+            visited_insert(vs, nullptr, cur_id, vis_ovf, used_ovf);
         }
         n_ovf = __ballot(lane == 0 && used_ovf) ? 1u : 0u;
 #pragma unroll
@@ -853,13 +877,29 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
             st.n_expand++;
             for (uint32_t b0 = 0;;) {
                 DIAG_STAMP(t1b);
-                if (nvis + 64 > visit_limit || n_ovf + 64 > ovf_limit) { fail = 1; break; }
+                if (nvis + 64 > visit_limit) { fail = 1; break; }
+                if (n_ovf + 64 > ovf_limit) {
+                    // the overflow table is at its limit: continue in a spill table in device memory, taken from the
+                    // launch's pool (the queries that get here are few; one that finds the pool empty is re-run)
+                    if (!spill) {
+                        uint32_t t = 0;
+                        if (lane == 0) t = atomicAdd(&a.fail_count[3], 1u);
+                        t = rfl(t);
+                        if (t >= a.spill_tables) { fail = 1; break; }
+                        spill = a.spill_pool + (size_t)t * a.spill_slots;
+                        for (uint32_t i = lane; i < a.spill_slots; i += 64) spill[i] = kEmpty;
+                        __threadfence();
+                    } else if (n_spill + 64 > spill_limit) { fail = 1; break; }
+                }
                 const bool live = my != kEmpty;
                 const uint32_t nlive = (uint32_t)__popcll(__ballot(live));
                 used_ovf = false;
-                const bool fresh = live && visited_insert(vs, my, vis_ovf, used_ovf);
+                const bool fresh = live && visited_insert(vs, spill, my, vis_ovf, used_ovf);
                 if (__ballot(vis_ovf)) { fail = 1; break; }
-                n_ovf += (uint32_t)__popcll(__ballot(fresh && used_ovf));
+                {
+                    const uint32_t added = (uint32_t)__popcll(__ballot(fresh && used_ovf));
+                    if (spill) n_spill += added; else n_ovf += added;
+                }
                 const uint32_t m = (uint32_t)__popcll(__ballot(fresh));
                 st.sum_deg0 += nlive; st.n_dist += m; nvis += m;
                 LDS_SYNC();
@@ -1032,6 +1072,9 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
         const uint32_t vmax = st.n_visited0 > st.n_visited_up ? st.n_visited0 : st.n_visited_up;
         if (vmax > __hip_atomic_load(&a.fail_count[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&a.fail_count[1], vmax);
         if (c_need > __hip_atomic_load(&a.fail_count[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&a.fail_count[2], c_need);
+        // (the mean from one query in 32: atomics to one address are served one after the other, and ten thousand
+        // of them take longer than a whole batch)
+        if ((qi & 31u) == 0u) { atomicAdd(&a.fail_count[4], vmax >> 4); atomicAdd(&a.fail_count[5], 1u); }
 #endif
     }
 }
@@ -1097,6 +1140,8 @@ void DeviceIndex::release()
     if (device >= 0) (void)hipSetDevice(device);
     for (auto& b : bufs_) { if (b) (void)hipFree(b); b = nullptr; }
     if (d_fail) (void)hipFree(d_fail);
+    if (d_spill) (void)hipFree(d_spill);
+    d_spill = nullptr;
     if (h_fail) (void)hipHostFree(h_fail);
     d_fail = nullptr; h_fail = nullptr; fail_cap = 0;
     version = ~0ull;
@@ -1176,7 +1221,8 @@ void DeviceIndex::upload(const HostIndex& h, int dev)
     if (!h_fail) HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_fail), 64, hipHostMallocDefault));
     (void)noalloc_scratch_for(dev, true);
     version = h.version_;
-    learn_flags = 0; learn_ef = 0; learn_visit = 0; learn_c = 0;
+    learn_flags = 0; learn_ef = 0; learn_visit = 0; learn_c = 0; learn_mean = 0;
+    shape_full = BucketShape{}; shape_bulk = BucketShape{};
 }
 
 void DeviceIndex::ensure_quantized(const HostIndex& h)
@@ -1271,22 +1317,22 @@ static bool visited16_shape(uint32_t n, uint32_t want_visit, uint32_t rb_min, ui
     return true;
 }
 
-// The bucket form for `want_visit` ids below n: 2^rb regions of 8 * nchunk 16-bit slots plus an overflow table
-// of ovf_slots 32-bit slots (one slot of every region holds its fill count), the combination with the fewest bytes.  A region receives a Poisson share of the
-// visited ids (the low id bits of the nodes a search meets are as good as random); what does not fit goes to
-// the overflow table, which is sized for the expected total plus four standard deviations plus one batch.
-static bool bucket_shape(uint32_t n, uint32_t want_visit, uint32_t rb_min, uint32_t& rb, uint32_t& nchunk, uint32_t& ovf_slots)
+// The bucket form for `want_visit` ids below n: `regions` regions of 8 * nchunk 16-bit slots plus an overflow table
+// of ovf_slots 32-bit slots (one slot of every region holds its fill count), the combination with the fewest bytes.
+// A region receives a Poisson share of the visited ids (the ids of the nodes a search meets are as good as random);
+// what does not fit goes to the overflow table, which is sized for the expected total plus four standard deviations
+// plus one batch.
+static bool bucket_shape(uint32_t n, uint32_t want_visit, uint32_t rb_min, uint32_t& regions, uint32_t& nchunk, uint32_t& ovf_slots)
 {
-    uint32_t rb0 = rb_min;
-    while (rb0 < 16 && ((n - 1u) >> rb0) >= 0xFFFFu) rb0++;
-    if (((n - 1u) >> rb0) >= 0xFFFFu) return false;
+    const uint32_t r_min = std::max<uint32_t>({(n - 1u) / 0xFFFFu + 1u, 1u << std::min(rb_min, 20u), 4u});   // tags stay below 0xFFFF
+    const uint32_t r_max = std::max<uint32_t>(r_min, (want_visit + 64u) / 4u);
     size_t best = ~(size_t)0;
-    for (uint32_t r = rb0; r <= rb0 + 8 && r <= 14; r++) {
-        const double R = (double)(1u << r), lambda = (double)(want_visit + 64u) / R;
+    for (uint32_t r = r_min; r <= r_max; r += std::max(1u, r / 32u)) {
+        const double R = (double)r, lambda = (double)(want_visit + 64u) / R;
         for (uint32_t c = 2; c <= 4; c++) {
             const uint32_t S = 8 * c;
-            if (lambda > 1.2 * S) continue;
-            // first and second moment of (X - U)+ for X ~ Poisson(lambda), U = S - 1 usable slots (one holds the count)
+            if (lambda > 1.2 * S || lambda < 0.4 * S) continue;
+            // first and second moment of (X - U)+ for X ~ Poisson(lambda), U = S - 1 usable slots
             const uint32_t U = S - 1u;
             double pk = exp(-lambda), e1 = 0.0, e2 = 0.0;
             for (uint32_t k = 1; k <= U + 96; k++) {
@@ -1296,12 +1342,15 @@ static bool bucket_shape(uint32_t n, uint32_t want_visit, uint32_t rb_min, uint3
             const double total = R * e1, sd = sqrt(std::max(0.0, R * (e2 - e1 * e1)));
             const uint32_t need = (uint32_t)(total + 4.0 * sd) + 64u;
             const uint32_t ovf = std::max(128u, hash32_slots(need));
-            const size_t bytes = (size_t)(1u << r) * S * 2 + (size_t)ovf * 4;
-            if (bytes < best) { best = bytes; rb = r; nchunk = c; ovf_slots = ovf; }
+            const size_t bytes = (size_t)r * S * 2 + (size_t)ovf * 4;
+            if (bytes < best) { best = bytes; regions = r; nchunk = c; ovf_slots = ovf; }
         }
     }
     return best != ~(size_t)0;
 }
+
+// Spill tables of the bucket form (device memory): a pool per index, 64 MB
+constexpr uint32_t kSpillTables = 1024, kSpillSlots = 16384;
 
 uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32_t out_k, uint32_t flags, uint32_t* d_ids,
                              float* d_dist, uint32_t* d_count, hnsw_amd_query_stats* d_stats, void* stream_v, bool sync_and_retry,
@@ -1362,9 +1411,14 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
     // count and candidate heap of every launch): the same ef and flags with a twentieth of headroom, another ef by
     // the ratio of observation to estimate at the ef it was made at (data on which searches visit several
     // times the estimate, such as unit-norm vectors under the reference's int32 keys, do so at every ef).
-    if (flags != learn_flags) { learn_flags = flags; learn_ef = 0; learn_visit = 0; learn_c = 0; }
+    if (flags != learn_flags) { learn_flags = flags; learn_ef = 0; learn_visit = 0; learn_c = 0; learn_mean = 0; }
     uint32_t want_visit0 = visit_estimate(ef), want_c0 = heap_estimate(ef);
+    // what the bulk of the queries needs (bucket form with spill tables: the few beyond it continue in device memory)
+    uint32_t want_bulk0 = 0;
     if (learn_ef == ef) {
+        float frac = 0.45f;
+        if (const char* e = getenv("HNSW_AMD_BULK_FRAC")) frac = (float)atof(e);      // tuning
+        if (learn_mean > 0 && learn_mean < learn_visit) want_bulk0 = learn_mean + (uint32_t)(frac * (float)(learn_visit - learn_mean));
         want_visit0 = learn_visit + learn_visit / 20u + 16u;
         want_c0 = learn_c + learn_c / 32u + 4u;          // (learn_c is what the overflow test asked for, not the heap's size)
     } else if (learn_ef != 0) {
@@ -1374,6 +1428,10 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
         want_c0 = (uint32_t)((float)want_c0 * std::min(rc, 16.0f));
     }
     if (const char* e = getenv("HNSW_AMD_WANT_VISIT")) want_visit0 = (uint32_t)atoi(e);      // diagnostics: a fixed size
+    const char* force_bulk = getenv("HNSW_AMD_WANT_BULK");                                   // tests: spill whatever it gains
+    if (force_bulk) want_bulk0 = (uint32_t)atoi(force_bulk);
+    uint32_t spill_tables = kSpillTables;
+    if (const char* e = getenv("HNSW_AMD_SPILL_TABLES")) spill_tables = std::min<uint32_t>(kSpillTables, (uint32_t)atoi(e));   // tests: a pool that runs dry
     uint32_t rb_min = 0;
     if (const char* e = getenv("HNSW_AMD_VIS_RB_MIN")) rb_min = (uint32_t)atoi(e);      // tests: the region count of a larger index
 
@@ -1381,8 +1439,10 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
     uint32_t* cur = list_a;
     uint32_t* other = list_b;
     uint32_t seen_visit = 0, seen_c = 0;
+    uint64_t seen_sum16 = 0, seen_done = 0;
     for (int tier = 0;; tier++) {
         const uint32_t want_visit = want_visit0 << tier;
+        a.spill_pool = nullptr; a.spill_tables = 0; a.spill_slots = 0; a.vis_regions = 0; a.vis_magic = 0;
         a.hash_size = hash32_slots(want_visit); a.vis_rb = 0xFFFFFFFFu; a.vis_chunks = 0; a.ovf_size = 0;
         a.cap_c = std::max(((want_c0 << tier) + 31u) & ~31u, ((uint32_t)ef + 33u) & ~31u);      // W is sorted in C's space at the end
         const bool std_heap = (flags & HNSW_AMD_W_STD_HEAP) != 0 || ef > 256;
@@ -1402,26 +1462,48 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
             // HNSW_AMD_VISITED32 / HNSW_AMD_VISITED16 / HNSW_AMD_VISITEDB force one form.
             const bool force16 = getenv("HNSW_AMD_VISITED16") != nullptr, forceb = getenv("HNSW_AMD_VISITEDB") != nullptr;
             if (!getenv("HNSW_AMD_VISITED32") && (force16 || forceb || lds > budget)) {
+                auto occupancy = [&](size_t bytes) {
+                    int occ = 0;
+                    if (bytes <= 65536) HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kern), 64, bytes));
+                    else occ = (int)(kLdsPerCu / bytes);
+                    return occ;
+                };
+                auto bucket_args = [&](uint32_t want, BucketShape& sh, SearchArgs& out) -> size_t {
+                    if (sh.n != g.n || sh.want != want || sh.rb_min != rb_min) {
+                        sh.ok = bucket_shape(g.n, want, rb_min, sh.regions, sh.chunks, sh.ovf);
+                        sh.n = g.n; sh.want = want; sh.rb_min = rb_min;
+                    }
+                    if (!sh.ok) return ~(size_t)0;
+                    out = a;
+                    out.hash_size = 8u * sh.chunks * sh.regions; out.vis_rb = 0; out.vis_chunks = sh.chunks; out.ovf_size = sh.ovf;
+                    out.vis_regions = sh.regions; out.vis_magic = (uint32_t)(0x100000000ull / sh.regions);
+                    return search_lds_bytes(out, std_heap);
+                };
                 SearchArgs b16 = a, bb = a;
                 size_t lds16 = ~(size_t)0, ldsb = ~(size_t)0;
-                uint32_t rb = 0, slots = 0, nchunk = 0, ovf = 0;
+                uint32_t rb = 0, slots = 0;
                 if (!forceb && visited16_shape(g.n, want_visit, rb_min, rb, slots)) {
                     b16.hash_size = slots; b16.vis_rb = rb;
                     lds16 = search_lds_bytes(b16, std_heap);
                 }
-                if (!force16 && bucket_shape(g.n, want_visit, rb_min, rb, nchunk, ovf)) {
-                    bb.hash_size = (8u * nchunk) << rb; bb.vis_rb = rb; bb.vis_chunks = nchunk; bb.ovf_size = ovf;
-                    ldsb = search_lds_bytes(bb, std_heap);
+                if (!force16) {
+                    ldsb = bucket_args(want_visit, shape_full, bb);
+                    // Tables for the bulk of the queries and spill tables for the rest, where that lets a CU hold more
+                    // queries (first tier only; HNSW_AMD_NO_SPILL: never)
+                    const bool spill_ok = tier == 0 && want_bulk0 > 0 && !getenv("HNSW_AMD_NO_SPILL") && (d_spill != nullptr || !no_alloc);
+                    if (spill_ok && ldsb != ~(size_t)0 && ldsb <= lds16) {
+                        SearchArgs bs = a;
+                        const size_t ldss = bucket_args(want_bulk0, shape_bulk, bs);
+                        if (ldss != ~(size_t)0 && (force_bulk || occupancy(ldss) > occupancy(ldsb))) {
+                            if (!d_spill) HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_spill), (size_t)kSpillTables * kSpillSlots * 4));
+                            bs.spill_pool = d_spill; bs.spill_tables = spill_tables; bs.spill_slots = kSpillSlots;
+                            bb = bs; ldsb = ldss;
+                        }
+                    }
                 }
                 const bool use_b = ldsb < lds16;
                 const size_t ldsn = use_b ? ldsb : lds16;
                 if (ldsn != ~(size_t)0) {
-                    auto occupancy = [&](size_t bytes) {
-                        int occ = 0;
-                        if (bytes <= 65536) HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kern), 64, bytes));
-                        else occ = (int)(kLdsPerCu / bytes);
-                        return occ;
-                    };
                     const int occ32 = occupancy(lds), occn = occupancy(ldsn);
                     // (beyond 16 queries per CU the cheaper 32-bit probe wins: measured on the byte-row kernel, 16 -> 20)
                     if (force16 || forceb || (occn > occ32 && occ32 < 16)) { a = use_b ? bb : b16; lds = ldsn; }
@@ -1451,7 +1533,8 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), 64, lds);
             char form[96];
             if (a.vis_rb == 0xFFFFFFFFu) snprintf(form, sizeof form, "%u slots of 32 bits", a.hash_size);
-            else if (a.vis_chunks) snprintf(form, sizeof form, "%u regions x %u slots of 16 bits + %u overflow", 1u << a.vis_rb, 8u * a.vis_chunks, a.ovf_size);
+            else if (a.vis_chunks) snprintf(form, sizeof form, "%u regions x %u slots of 16 bits + %u overflow%s", a.vis_regions, 8u * a.vis_chunks, a.ovf_size,
+                                            a.spill_tables ? " + spill tables" : "");
             else snprintf(form, sizeof form, "%u slots of 16 bits in %u regions", a.hash_size, 1u << a.vis_rb);
             fprintf(stderr, "[hnsw_amd] search launch: %u queries, ef=%d, tier %d (visited: %s for %u ids, C %u), LDS %zu B, resident queries per CU %d\n",
                     a.nq_launch, ef, tier, form, want_visit, a.cap_c, lds, nb);
@@ -1475,22 +1558,26 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
         const uint32_t nfail = h_fail[0];
         seen_visit = std::max(seen_visit, h_fail[1]);
         seen_c = std::max(seen_c, h_fail[2]);
+        seen_sum16 += h_fail[4]; seen_done += h_fail[5];
         if (getenv("HNSW_AMD_VERBOSE"))
-            fprintf(stderr, "[hnsw_amd]   %u of %u queries outgrew their scratch; largest visited set %u, largest C %u\n", nfail, a.nq_launch, h_fail[1], h_fail[2]);
+            fprintf(stderr, "[hnsw_amd]   %u of %u queries outgrew their scratch, %u used a spill table; largest visited set %u, room asked of C %u\n",
+                    nfail, a.nq_launch, std::min(h_fail[3], a.spill_tables), h_fail[1], h_fail[2]);
         if (nfail == 0) break;
         retried += nfail;
         a.qmap = cur + kFailHeader; a.nq_launch = nfail;
         std::swap(cur, other);
     }
     // remember what this batch needed (the maxima are those of the queries that finished, i.e. of all of them)
+    const uint32_t seen_mean = seen_done ? (uint32_t)(seen_sum16 * 16u / seen_done) : 0u;
     if (seen_visit == 0) {
         // (a diagnostic build of the kernel reports nothing)
     } else if (learn_ef == ef) {
         // grows at once, shrinks slowly (one far-reaching query should not cost residency for ever)
         learn_visit = std::max(seen_visit, (uint32_t)(((uint64_t)learn_visit * 15u + seen_visit) / 16u));
         learn_c = std::max(seen_c, (uint32_t)(((uint64_t)learn_c * 15u + seen_c) / 16u));
+        if (nq >= 64) learn_mean = (uint32_t)(((uint64_t)learn_mean * 3u + seen_mean) / 4u);
     } else if (nq >= 64 || learn_ef == 0) {
-        learn_ef = ef; learn_visit = seen_visit; learn_c = seen_c;
+        learn_ef = ef; learn_visit = seen_visit; learn_c = seen_c; learn_mean = nq >= 64 ? seen_mean : 0u;
     }
     return retried;
 }

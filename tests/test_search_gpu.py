@@ -209,3 +209,30 @@ def test_bucket_form_on_unit_norm_data_against_the_oracle(monkeypatch):
         assert_same_results(ids, dist, oi, od, what=f"deep ef={ef}")
         for f in st.dtype.names:
             assert np.array_equal(st[f], ost[f]), (ef, f)
+
+
+@pytest.mark.parametrize("tables", [None, 5])
+def test_bucket_form_spills_to_device_memory(monkeypatch, tables):
+    """Tables in LDS sized for far fewer nodes than the queries visit: the overflow table closes and the search
+    continues in a spill table in device memory; with a pool of only five tables most queries find it empty and are
+    re-run on larger tables instead.  Results and counters are the oracle's either way."""
+    from hnsw_amd import datagen
+    monkeypatch.setenv("HNSW_AMD_VISITEDB", "1")
+    monkeypatch.setenv("HNSW_AMD_VIS_RB_MIN", "8")
+    monkeypatch.setenv("HNSW_AMD_WANT_BULK", "900")
+    if tables is not None:
+        monkeypatch.setenv("HNSW_AMD_SPILL_TABLES", str(tables))
+    base = datagen.make("deep", 40000, seed=6)
+    q = datagen.make("deep", 400, seed=6, stream=1)
+    h = HNSW(16, 16, 100)
+    h.init(96, len(base))
+    h.insert_batch(base, threads=16)
+    idx = oracle.OracleIndex(h.export_flat(), base)
+    for ef in (30, 30, 80):
+        ids, dist, cnt, st = h.search_batch(q, ef, stats=True)
+        oi, od, oc, ost = idx.search(q, ef, stats=True)
+        assert ost["n_visited0"].max() > 1500          # the premise: far beyond the 900 the tables were sized for
+        assert np.array_equal(cnt, oc)
+        assert_same_results(ids, dist, oi, od, what=f"deep ef={ef} spill")
+        for f in st.dtype.names:
+            assert np.array_equal(st[f], ost[f]), (ef, f)

@@ -51,13 +51,18 @@ ENV = {"32": "HNSW_AMD_VISITED32", "16": "HNSW_AMD_VISITED16", "B": "HNSW_AMD_VI
 for ef in [int(x) for x in a.ef.split(",")]:
     ref = None
     for form in a.forms.split(","):
-        for v in ENV.values():
+        for v in list(ENV.values()) + ["HNSW_AMD_BULK_FRAC", "HNSW_AMD_NO_SPILL"]:
             os.environ.pop(v, None)
-        if form in ENV:
-            os.environ[ENV[form]] = "1"
+        name, _, opt = form.partition(":")           # e.g. auto:0.25 = bulk fraction 0.25, auto:nospill
+        if name in ENV:
+            os.environ[ENV[name]] = "1"
+        if opt == "nospill":
+            os.environ["HNSW_AMD_NO_SPILL"] = "1"
+        elif opt:
+            os.environ["HNSW_AMD_BULK_FRAC"] = opt
         try:
             os.environ["HNSW_AMD_VERBOSE"] = "1"
-            for _ in range(2):      # discovery + sized-from-observation
+            for _ in range(3):      # discovery, sized from observation, bulk sizing
                 retried = h.search_batch_device(q_t.data_ptr(), nq, ef, 10, ids.data_ptr(), ds.data_ptr(), cnt.data_ptr(), st_t.data_ptr(), stream, flags)
             os.environ.pop("HNSW_AMD_VERBOSE")
             retried = h.search_batch_device(q_t.data_ptr(), nq, ef, 10, ids.data_ptr(), ds.data_ptr(), cnt.data_ptr(), st_t.data_ptr(), stream, flags)
