@@ -44,7 +44,7 @@ def main():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--ef", type=int, default=0, help="0 = smallest ef of the reference sweep with recall@10 >= target")
     ap.add_argument("--target-recall", type=float, default=0.95)
-    ap.add_argument("--build-threads", type=int, default=16)
+    ap.add_argument("--build-threads", type=int, default=0, help="0 = this rank's share of the usable host cores")
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "port", "reference", "none"],
                     help="auto: the unmodified reference binary (oracle/_ref) when present, else the CPU restatement")
     ap.add_argument("--cpu-sample", type=int, default=4000)
@@ -89,11 +89,16 @@ def main():
     # handling of device tensors is not used)
     cdev = dev if backend == "nccl" else torch.device("cpu")
     if world > 1:
+        import datetime
+        # (index builds of different length run between collectives: a generous limit for the slowest rank)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(minutes=45))
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=datetime.timedelta(minutes=45))
 
+    if args.build_threads <= 0:
+        # every rank builds at the same time on the one host: share its cores
+        args.build_threads = max(1, harness.usable_cores() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world))))
     d = datagen.KINDS[args.kind]
     k = args.k
     # ---- shard of the base set, queries ----
@@ -178,7 +183,7 @@ def main():
     if parts == 1 and rank == 0:
         from oracle import oracle as _oracle
         samp = np.linspace(0, args.nq - 1, 16).astype(int)
-        cpu_gt = _oracle.bruteforce(base, queries[samp], k, threads=min(16, os.cpu_count() or 1)).astype(np.int64)
+        cpu_gt = _oracle.bruteforce(base, queries[samp], k, threads=harness.usable_cores()).astype(np.int64)
         gsub = gi[torch.from_numpy(samp).to(dev)].cpu().numpy()[:, :k]
         dd = lambda ids: ((queries[samp][:, None, :].astype(np.float64) - base[ids].astype(np.float64)) ** 2).sum(-1)
         gt_info["cpu_double_check"] = bool(np.array_equal(dd(gsub), dd(cpu_gt)))    # same distances: equal up to exact ties
@@ -325,15 +330,33 @@ def main():
         torch.cuda.synchronize()
         copy_gbs = 5 * 2 * ca.numel() * 4 / (c0.elapsed_time(c1) * 1e-3) / 1e9
         del ca, cb
+    # How the timed launches were configured, and what this GPU delivers for the same row reads with all search logic
+    # removed (random rows of this index's own table, same loads and arithmetic, same residency): the ceiling the
+    # achieved rate can be compared with when the peak of the memory is not reachable by a gather.
+    launch_info, ceiling_gbs = None, None
+    if rank == 0:
+        h.search_batch_device(q_t.data_ptr(), nq, ef, k, ids_t.data_ptr(), dist_t.data_ptr(), cnt_t.data_ptr(), 0,
+                              torch.cuda.current_stream().cuda_stream, flags)
+        torch.cuda.synchronize()
+        launch_info = h.last_launch_info()
+        if args.rows == "f32" and args.dist == "sse":
+            rows_per_wave = max(32, int(round(float(st["n_dist"].mean()) / 32.0)) * 32)
+            c_ms, c_bytes = h.gather_ceiling(nq, rows_per_wave, launch_info["lds_bytes_per_query"], torch.cuda.current_stream().cuda_stream)
+            ceiling_gbs = c_bytes / (c_ms * 1e-3) / 1e9
     # HBM bytes per launch from the PMC passes of tools/pmc_passes.sh over this same workload
     # (FETCH_SIZE doubled as the gfx950 counter requires, plus WRITE_SIZE); a profile of
     # another workload does not apply
-    traffic = None
+    traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "pmc_search_kernel_latest.json")
     if world == 1 and os.path.exists(tpath) and args.n == 1_000_000 and nq == 10_000 and args.kind == "sift" and ef == 50 and args.rows == "f32":
         with open(tpath) as f:
             pm = json.load(f)
         traffic = pm.get("hbm_read_bytes_x2", 0) + pm.get("hbm_write_bytes", 0) or None
+        traffic_source = {"file": "profiles/pmc_search_kernel_latest.json",
+                          "collected": "an earlier run of tools/pmc_passes.sh on this workload (rocprofv3 --pmc passes), not this run",
+                          "counters": "2 x FETCH_SIZE + WRITE_SIZE of one launch; they count the L2's fabric-side requests, "
+                                      "Infinity-Cache hits included, so this is not DRAM traffic alone"}
+    table_bytes = (hi - lo) * ((d + 31) // 32 * 32) * 4 + (hi - lo) * 32 * 4        # stored rows + layer-0 lists on this GPU
 
     # ---- N=1: the same search on a batch four times as large (not part of `value`): the 10 000-query batch of the
     #      configuration is ~2.4 rounds of resident queries, so ramp-up and the last partial round weigh on it ----
@@ -394,27 +417,46 @@ def main():
                     out = subprocess.run([drv, "ltime", gpath, "16", "16", "200", qpath, str(ns), str(ef), "30"],
                                          capture_output=True, text=True, check=True, timeout=150).stderr
                     rec = json.loads(out.strip().splitlines()[-1])
-                    # full-size parity against the reference itself: its W_ for a sample of the queries
-                    npar = min(1000, ns)
+                    # full-size parity against the reference itself: its complete W_ (all ef entries) for every timed query
+                    npar = ns
                     subprocess.run([drv, "lquery", gpath, "16", "16", "200", qpath, str(npar), rpath, str(ef)], check=True,
-                                   capture_output=True, timeout=150)
-                    r_ids, r_d, _ = oracle.parse_ref_results(rpath)[ef]
-                    log(f"reference binary: save + load + timing + {npar}-query dump in {time.time() - t0:.1f}s")
-                g_ids = out_ids.cpu().numpy().view(np.uint32)[:npar]
-                g_d = out_dist.cpu().numpy()[:npar]
+                                   capture_output=True, timeout=300)
+                    r_ids, r_d, r_cnt = oracle.parse_ref_results(rpath)[ef]
+                    # the reference driver's own "Precision" (src/main.cpp:236-280) from the reference's own W_, all queries
+                    apath, gtpath = os.path.join(tmp, "qa.bin"), os.path.join(tmp, "gt.bin")
+                    queries.tofile(apath)
+                    np.ascontiguousarray(gt[:, :k], dtype=np.uint32).tofile(gtpath)
+                    pout = subprocess.run([drv, "lprecision", gpath, "16", "16", "200", apath, str(nq), gtpath, str(k), str(max(ef, k + 1))],
+                                          capture_output=True, text=True, check=True, timeout=300).stderr
+                    ref_prec = json.loads(pout.strip().splitlines()[-1])["ref_precision"]
+                    log(f"reference binary: save + load + timing + {npar}-query dump + precision over {nq} queries in {time.time() - t0:.1f}s")
+                h.search_batch_device(q_t.data_ptr(), npar, ef, ef, ids_t.data_ptr(), dist_t.data_ptr(), cnt_t.data_ptr(), 0,
+                                      torch.cuda.current_stream().cuda_stream, flags)
+                torch.cuda.synchronize()
+                g_ids = ids_t.view(-1)[:npar * ef].view(npar, ef).cpu().numpy().view(np.uint32)
+                g_d = dist_t.view(-1)[:npar * ef].view(npar, ef).cpu().numpy()
+                g_cnt = cnt_t[:npar].cpu().numpy().view(np.uint32)
                 try:
-                    assert_same_results(g_ids, g_d, r_ids[:, :k], r_d[:, :k], what="GPU vs reference binary")
+                    assert np.array_equal(g_cnt, r_cnt), "|W_| differs"
+                    assert_same_results(g_ids, g_d, r_ids, r_d, what="GPU vs reference binary")
                     same = True
                 except AssertionError as e:
                     log(f"PARITY FAILURE against the reference binary: {e}")
                     same = False
+                prec_ok = prec_ref is not None and abs(prec_ref - ref_prec) <= 0.001
+                if not prec_ok:
+                    log(f"PRECISION MISMATCH: reference binary {ref_prec} vs this library {prec_ref}")
                 cpu = {"value": round(rec["qps"], 1), "unit": "queries/s", "cores": 1, "kind": "reference",
                        "sample": f"first {ns} queries, ef={ef}, min of {rec['passes']} passes, 1 thread; unmodified reference binary, "
                                  f"index read by its own loadGraph from the file this library saved",
-                       "gpu_top10_equals_reference_on_first": npar, "parity": same}
+                       "gpu_W_equals_reference_W_on_first": npar, "W_entries_compared": int(npar * ef), "parity": same,
+                       "reference_precision": round(ref_prec, 5), "reference_precision_queries": nq,
+                       "precision_delta": round(abs(prec_ref - ref_prec), 6) if prec_ref is not None else None,
+                       "precision_within_0.001": bool(prec_ok),
+                       "host_cpu_model": harness.cpu_model(), "host_cores": os.cpu_count()}
                 # the reference object cannot be shared between threads (a query writes to it, src/hnsw.cpp:380), so the
                 # many-core figure is the CPU restatement's: one private scratch per thread over the shared flat graph
-                nt = min(16, os.cpu_count() or 1)
+                nt = harness.usable_cores()
                 idx = oracle.OracleIndex(h.export_flat(), base)
                 t0 = time.perf_counter()
                 idx.search(queries, ef, out_k=k, threads=nt, dist_mode=1 if args.dist == "scalar" else 0, key_mode=0)
@@ -433,7 +475,7 @@ def main():
                 o_ids, o_d, _ = idx.search(queries[:ns], ef, out_k=k, threads=1, dist_mode=1 if args.dist == "scalar" else 0,
                                             key_mode=1 if args.keys == "float" else 0)
                 best = min(best, time.perf_counter() - t0)
-            nt = min(16, os.cpu_count() or 1)
+            nt = harness.usable_cores()
             t0 = time.perf_counter()
             idx.search(queries, ef, out_k=k, threads=nt, dist_mode=1 if args.dist == "scalar" else 0, key_mode=1 if args.keys == "float" else 0)
             mt = time.perf_counter() - t0
@@ -441,7 +483,8 @@ def main():
             cpu = {"value": round(ns / best, 1), "unit": "queries/s", "cores": 1, "kind": "port",
                    "sample": f"first {ns} queries, ef={ef}, min of 3 passes, 1 thread (CPU restatement, bit-equal to the reference)",
                    "mt": {"value": round(nq / mt, 1), "cores": nt},
-                   "gpu_distances_bit_equal_on_sample": same}
+                   "gpu_distances_bit_equal_on_sample": same,
+                   "host_cpu_model": harness.cpu_model(), "host_cores": os.cpu_count()}
             if ref_note:
                 cpu["note"] = ref_note
 
@@ -454,15 +497,24 @@ def main():
         fpath = os.path.join(tempfile.gettempdir(), f"hnsw_amd_bench_full_{os.environ.get('MASTER_PORT', '0')}_{args.kind}_{args.n}.npz")
         full = datagen.make(args.kind, args.n, seed=1, stream=0)
         hf = HNSW(16, 16, 200, device=local_rank)
+        if rank == 0 and os.path.exists(fpath):
+            os.remove(fpath)
+        dist.barrier()                                  # (so that no rank still reads a file of an earlier run)
         if rank == 0:                                   # one build for the node, handed over through a local file
             hf.init(d, args.n)
+            nt_full = harness.usable_cores()            # the other ranks wait: the whole share of the host
             for r0 in range(0, args.n, 500_000):
-                hf.insert_batch(full[r0:r0 + 500_000], threads=args.build_threads)
+                hf.insert_batch(full[r0:r0 + 500_000], threads=nt_full)
                 log(f"alongside: inserted {min(args.n, r0 + 500_000)} / {args.n} in {time.time() - t0:.0f}s")
             np.savez(fpath + ".tmp.npz", **hf.export_flat().to_npz_dict())
             os.replace(fpath + ".tmp.npz", fpath)
-        dist.barrier()
-        if rank != 0:
+        else:
+            # wait on the host for the file, not inside a collective on the GPU, however long the build takes
+            limit = time.time() + 2400
+            while not os.path.exists(fpath):
+                if time.time() > limit:
+                    raise SystemExit("alongside: rank 0 did not deliver the index file")
+                time.sleep(0.5)
             hf.import_flat(FlatGraph.from_npz(np.load(fpath)), full)
         dist.barrier()
         if rank == 0:
@@ -528,12 +580,25 @@ def main():
                                    f"keys={args.keys}, rows={args.rows}" + (f", {world} shards + RCCL all-gather + device merge" if parts > 1 else "")
                                    + (f", index replicated on {world} GPUs, {nq} queries each" if world > 1 and parts == 1 else ""),
                        "ef": ef, "recall_at_10": round(recall, 4), "reference_precision_top11": prec_ref,
+                       "timed_step_output": f"the first k={k} entries of every W_ (the reference leaves all ef entries sorted in W_; "
+                                            f"the parity check of the cpu_baseline leg compares all ef)",
                        "ef_sweep": sweep, "build_s": round(build_s, 1), "build_threads": args.build_threads, "build_keys": args.build_keys,
                        "ground_truth": dict(gt_info, method="exact brute force, f32-input MFMA kernel of this library")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "measured_copy_gbs": round(copy_gbs, 1) if copy_gbs else None,
                          "frac_of_measured_copy": round(achieved / copy_gbs, 4) if copy_gbs else None,
+                         "traffic_source": traffic_source,
+                         "gather_ceiling_gbs": round(ceiling_gbs, 1) if ceiling_gbs else None,
+                         "frac_of_gather_ceiling": round(achieved / ceiling_gbs, 4) if ceiling_gbs else None,
+                         "gather_ceiling_is": "random rows of this index's table read with the search kernel's loads and distance "
+                                              "arithmetic, same residency, no search logic; measured in this run",
+                         "working_set_bytes": table_bytes,
+                         "infinity_cache_bytes": 256 << 20,
+                         "infinity_cache_share_of_working_set": round(min(1.0, (256 << 20) / table_bytes), 3),
+                         "note": "peak is the HBM specification; reads served by the 256 MiB Infinity Cache count as achieved bytes too, "
+                                 "so with a working set of a few hundred MB part of the achieved rate is on-die, not DRAM",
+                         "launch": launch_info,
                          "kernel": "hnsw_search_kernel", "kernel_ms": round(kern_ms, 4),
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "bytes_per_query": round(bytes_per_launch / nq, 1)},

@@ -59,6 +59,7 @@ int main(int argc, char** argv)
         if (ef > 100) ef += 10;
         // one query at a time, as the reference's loop
         double positive = 0;
+        auto t_one = std::chrono::steady_clock::now();
         for (size_t i = 0; i < qsize; i++) {
             hnsw.aproximateKnn(&massQ[i * vecdim], k, ef);
             std::vector<uint32_t> result;
@@ -67,7 +68,8 @@ int main(int argc, char** argv)
             for (uint32_t c2 = 0; c2 < k; c2++)
                 if (std::find(result.begin(), result.end(), massQA[i * answer_size + c2]) != result.end()) positive++;
         }
-        std::cout << "Precision: " << positive / (qsize * k) << ", ef: " << ef << ", ";
+        const double us_one = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_one).count() / qsize;
+        std::cout << "Precision: " << positive / (qsize * k) << ", ef: " << ef << ", one query per call: " << us_one << " [us], ";
         // batched: three timed passes, minimum
         double best = 1e30, positive_b = 0;
         for (int pass = 0; pass < 3; pass++) {

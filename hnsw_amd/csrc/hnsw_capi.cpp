@@ -29,10 +29,11 @@ struct hnsw_amd_index {
     DeviceIndex dev;
     int device = 0;
     FlatGraph exported;
-    // grow-only device staging of the host-pointer search entry points
-    void* d_q = nullptr; size_t q_bytes = 0;
-    void* d_ids = nullptr; void* d_dist = nullptr; size_t out_elems = 0;
-    void* d_cnt = nullptr; void* d_stats = nullptr; size_t nq_cap = 0;
+    // grow-only staging of the host-pointer search entry points: queries and the packed results
+    // (ids | distances | counts | counters) on the device, and pinned host mirrors of both, so that a call is
+    // two asynchronous copies around the kernel and one wait
+    void* d_q = nullptr; void* h_q = nullptr; size_t q_bytes = 0;
+    void* d_out = nullptr; void* h_out = nullptr; size_t out_bytes = 0;
     hnsw_amd_index(int M, int Mmax, int efC) : host(M, Mmax, efC) {}
 };
 
@@ -85,7 +86,8 @@ void hnsw_amd_destroy(hnsw_amd_index* h)
 {
     if (!h) return;
     if (h->dev.device >= 0) (void)hipSetDevice(h->dev.device);
-    for (void* p : {h->d_q, h->d_ids, h->d_dist, h->d_cnt, h->d_stats}) if (p) (void)hipFree(p);
+    for (void* p : {h->d_q, h->d_out}) if (p) (void)hipFree(p);
+    for (void* p : {h->h_q, h->h_out}) if (p) (void)hipHostFree(p);
     delete h;
 }
 
@@ -164,27 +166,34 @@ int hnsw_amd_search_batch(hnsw_amd_index* h, const float* queries, uint32_t nq, 
         HIP_OK(hipSetDevice(h->device));
         const size_t qb = (size_t)nq * h->host.vector_size_ * sizeof(float);
         const size_t oe = (size_t)nq * out_k;
-        if (qb > h->q_bytes) { if (h->d_q) HIP_OK(hipFree(h->d_q)); h->d_q = nullptr; HIP_OK(hipMalloc(&h->d_q, qb)); h->q_bytes = qb; }
-        if (oe > h->out_elems) {
-            if (h->d_ids) HIP_OK(hipFree(h->d_ids));
-            if (h->d_dist) HIP_OK(hipFree(h->d_dist));
-            h->d_ids = h->d_dist = nullptr;
-            HIP_OK(hipMalloc(&h->d_ids, oe * 4)); HIP_OK(hipMalloc(&h->d_dist, oe * 4)); h->out_elems = oe;
+        const size_t ob = (2 * oe + (size_t)nq) * 4 + (size_t)nq * sizeof(hnsw_amd_query_stats);
+        if (qb > h->q_bytes) {
+            if (h->d_q) HIP_OK(hipFree(h->d_q));
+            if (h->h_q) HIP_OK(hipHostFree(h->h_q));
+            h->d_q = h->h_q = nullptr; h->q_bytes = 0;
+            HIP_OK(hipMalloc(&h->d_q, qb)); HIP_OK(hipHostMalloc(&h->h_q, qb, hipHostMallocDefault)); h->q_bytes = qb;
         }
-        if (nq > h->nq_cap) {
-            if (h->d_cnt) HIP_OK(hipFree(h->d_cnt));
-            if (h->d_stats) HIP_OK(hipFree(h->d_stats));
-            h->d_cnt = h->d_stats = nullptr;
-            HIP_OK(hipMalloc(&h->d_cnt, (size_t)nq * 4)); HIP_OK(hipMalloc(&h->d_stats, (size_t)nq * sizeof(hnsw_amd_query_stats)));
-            h->nq_cap = nq;
+        if (ob > h->out_bytes) {
+            if (h->d_out) HIP_OK(hipFree(h->d_out));
+            if (h->h_out) HIP_OK(hipHostFree(h->h_out));
+            h->d_out = h->h_out = nullptr; h->out_bytes = 0;
+            HIP_OK(hipMalloc(&h->d_out, ob)); HIP_OK(hipHostMalloc(&h->h_out, ob, hipHostMallocDefault)); h->out_bytes = ob;
         }
-        HIP_OK(hipMemcpy(h->d_q, queries, qb, hipMemcpyHostToDevice));
-        h->dev.search((const float*)h->d_q, nq, ef, out_k, flags, (uint32_t*)h->d_ids, (float*)h->d_dist, (uint32_t*)h->d_cnt,
-                      (hnsw_amd_query_stats*)h->d_stats, nullptr, true);
-        HIP_OK(hipMemcpy(out_ids, h->d_ids, oe * 4, hipMemcpyDeviceToHost));
-        HIP_OK(hipMemcpy(out_dist, h->d_dist, oe * 4, hipMemcpyDeviceToHost));
-        if (out_count) HIP_OK(hipMemcpy(out_count, h->d_cnt, (size_t)nq * 4, hipMemcpyDeviceToHost));
-        if (stats) HIP_OK(hipMemcpy(stats, h->d_stats, (size_t)nq * sizeof(hnsw_amd_query_stats), hipMemcpyDeviceToHost));
+        uint32_t* d_ids = static_cast<uint32_t*>(h->d_out);
+        float* d_dist = reinterpret_cast<float*>(d_ids + oe);
+        uint32_t* d_cnt = d_ids + 2 * oe;
+        hnsw_amd_query_stats* d_stats = reinterpret_cast<hnsw_amd_query_stats*>(d_cnt + nq);
+        std::memcpy(h->h_q, queries, qb);
+        HIP_OK(hipMemcpyAsync(h->d_q, h->h_q, qb, hipMemcpyHostToDevice, nullptr));
+        // the results travel back behind every launch of the call, ahead of the wait that learns whether a launch
+        // has to be repeated for some queries (rare); the last copy is the one that counts
+        const DeviceIndex::CopyBack back{h->h_out, h->d_out, stats ? ob : ob - (size_t)nq * sizeof(hnsw_amd_query_stats)};
+        h->dev.search((const float*)h->d_q, nq, ef, out_k, flags, d_ids, d_dist, d_cnt, stats ? d_stats : nullptr, nullptr, true, false, &back);
+        const uint32_t* r = static_cast<const uint32_t*>(h->h_out);
+        std::memcpy(out_ids, r, oe * 4);
+        std::memcpy(out_dist, r + oe, oe * 4);
+        if (out_count) std::memcpy(out_count, r + 2 * oe, (size_t)nq * 4);
+        if (stats) std::memcpy(stats, r + 2 * oe + nq, (size_t)nq * sizeof(hnsw_amd_query_stats));
     });
 }
 
@@ -276,6 +285,36 @@ int hnsw_amd_merge_topk_device(const float* d_dist, const uint32_t* d_ids, const
     return guarded([&] {
         REQUIRE(d_dist && d_ids && shard_offset && d_out_ids && d_out_dist, "merge_topk_device: NULL argument");
         merge_topk(d_dist, d_ids, shard_offset, n_shards, nq, k, out_k, (size_t)shard_stride, d_out_ids, d_out_dist, stream);
+    });
+}
+
+int hnsw_amd_gather_ceiling_device(hnsw_amd_index* h, uint32_t n_waves, uint32_t rows_per_wave, uint32_t lds_bytes_per_wave, void* stream,
+                                   float* ms, uint64_t* bytes)
+{
+    return guarded([&] {
+        REQUIRE(h && ms && bytes, "gather_ceiling_device: NULL argument");
+        ensure_device_copy(h);
+        *ms = h->dev.gather_ceiling(n_waves, rows_per_wave, lds_bytes_per_wave, stream, *bytes);
+    });
+}
+
+int hnsw_amd_last_launch_info(hnsw_amd_index* h, uint32_t* lds_bytes_per_query, uint32_t* resident_queries_per_cu, uint32_t* visited_form)
+{
+    return guarded([&] {
+        REQUIRE(h, "last_launch_info: index is NULL");
+        uint32_t lds = 0, occ = 0, form = 0;
+        h->dev.last_launch(lds, occ, form);
+        if (lds_bytes_per_query) *lds_bytes_per_query = lds;
+        if (resident_queries_per_cu) *resident_queries_per_cu = occ;
+        if (visited_form) *visited_form = form;
+    });
+}
+
+int hnsw_amd_vector_data(hnsw_amd_index* h, const float** out)
+{
+    return guarded([&] {
+        REQUIRE(h && out, "vector_data: NULL argument");
+        *out = h->host.vector_data_.empty() ? nullptr : h->host.vector_data_.data();
     });
 }
 

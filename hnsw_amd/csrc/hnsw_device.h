@@ -68,6 +68,7 @@ public:
     uint32_t* d_fail = nullptr;       // [0] = count, [1..] list
     uint32_t fail_cap = 0;
     uint32_t* h_fail = nullptr;       // pinned host mirror of the list header
+    void* ev_done = nullptr;          // hipEvent_t the search calls wait on (created at upload)
     uint32_t* d_spill = nullptr;      // pool of spill tables (bucket form of the visited set), allocated on first need
     // largest visited set and candidate heap the queries of earlier batches reached, and the ef / flags they were
     // observed at: later batches are sized from them
@@ -88,9 +89,21 @@ public:
     // Returns the number of re-run queries; throws on HIP errors / scratch exhaustion.
     // no_alloc: the overflow lists live in the library's static device array instead of a buffer of this object
     // (no allocation of any kind inside the call; the array is shared by all calls on the GPU).
+    // The first launch of the last search call: dynamic LDS bytes per query, queries a CU holds with that, and the
+    // form of the visited set (0: 32-bit slots, 1: 16-bit probing regions, 2: 16-bit bucket regions).
+    void last_launch(uint32_t& lds_bytes, uint32_t& resident_per_cu, uint32_t& visited_form) const;
+    const void* last_kernel = nullptr;
+    uint32_t last_lds = 0;
+    int last_form = 0;
+    // Diagnostic: milliseconds of one launch in which n_waves wavefronts each read rows_per_wave random rows of the
+    // vector table with the search kernel's loads and distance arithmetic and nothing else; `bytes` = what the
+    // search's counters would charge for those rows.  lds_bytes per wavefront sets the residency.
+    float gather_ceiling(uint32_t n_waves, uint32_t rows_per_wave, uint32_t lds_bytes, void* stream, uint64_t& bytes);
+    // copy_back: a device-to-host copy (pinned destination) queued behind every launch, before the wait.
+    struct CopyBack { void* dst; const void* src; size_t bytes; };
     uint32_t search(const float* d_queries, uint32_t nq, int ef, uint32_t out_k, uint32_t flags, uint32_t* d_ids,
                     float* d_dist, uint32_t* d_count, hnsw_amd_query_stats* d_stats, void* stream, bool sync_and_retry,
-                    bool no_alloc = false);
+                    bool no_alloc = false, const CopyBack* copy_back = nullptr);
 
 private:
     void* bufs_[8] = {};

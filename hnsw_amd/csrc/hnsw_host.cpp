@@ -377,7 +377,7 @@ void HostIndex::insert_one(uint32_t id, const float* q, int level, const uint32_
         search_layer<MT>(i, q, efConstruction_, s);
         select_neighbors(s.W, s.R, M_, i);
         link<MT>(i, ns, id, s.R, s);
-        if (prev_layer >= 0) layers_[prev_layer].down[prev_slot] = ns;
+        if (!MT && prev_layer >= 0) layers_[prev_layer].down[prev_slot] = ns;      // (the concurrent path set it in add_node, before any other thread could see the node)
         prev_slot = ns; prev_layer = i;
         if (i > 0) change_layer(i, s.W);
     }
@@ -649,7 +649,50 @@ void HostIndex::save_graph(const char* filename) const
     if (!f) throw std::ios_base::failure(std::string("write to ") + filename + " failed");
 }
 
+// Everything a search trusts about a graph that came from a file: the same checks import_flat applies to
+// flat arrays.  (The GPU kernels index the vector table and the adjacency arrays with these numbers.)
+void HostIndex::validate_loaded(const char* filename) const
+{
+    auto bad = [&](const char* what) { return std::domain_error(std::string(filename) + ": " + what); };
+    const uint32_t n = layers_[0].count;
+    if (n == 0 || n > (uint32_t)max_node_count_) throw bad("layer 0 is empty or larger than the vector table");
+    for (size_t l = 0; l < layers_.size(); l++) {
+        const LayerStore& L = layers_[l];
+        if (L.deg > 64) throw bad("neighbour lists longer than 64 are not supported");
+        if (l > 0 && L.count > layers_[l - 1].count) throw bad("a layer larger than the one below it");
+        for (uint32_t s = 0; s < L.count; s++) {
+            if (L.order[s] >= n) throw bad("node outside layer 0");
+            const uint32_t* no = &L.nb_order[(size_t)s * L.deg];
+            const uint32_t* ns = &L.nb_slot[(size_t)s * L.deg];
+            for (uint32_t j = 0; j < L.cnt[s]; j++) {
+                if (no[j] >= n || ns[j] >= L.count) throw bad("neighbour outside the filled part of the index");
+                if (L.order[ns[j]] != no[j]) throw bad("a neighbour's position and its node_order disagree");
+                for (uint32_t jj = 0; jj < j; jj++)
+                    if (no[jj] == no[j]) throw bad("duplicate neighbour in a list");
+            }
+        }
+        if (L.ep_slot >= L.count || L.order[L.ep_slot] != L.ep_order) throw bad("entry point and its node_order disagree");
+    }
+}
+
+// The file is read into a separate object and adopted only when it parsed and validated: an error leaves this
+// index as it was.
 void HostIndex::load_graph(const char* filename)
+{
+    HostIndex tmp(M_, Mmax_ , efConstruction_);
+    tmp.Mmax0_ = Mmax0_;
+    tmp.parse_graph_file(filename);
+    tmp.validate_loaded(filename);
+    Mmax_ = tmp.Mmax_; Mmax0_ = tmp.Mmax0_;
+    vector_size_ = tmp.vector_size_; max_node_count_ = tmp.max_node_count_; actual_node_count_ = tmp.actual_node_count_;
+    layers_ = std::move(tmp.layers_);
+    vector_data_ = std::move(tmp.vector_data_);
+    rng_ = std::make_unique<GlibcRand>(1);
+    locks_.clear(); lock_cap_.clear();
+    version_++;
+}
+
+void HostIndex::parse_graph_file(const char* filename)
 {
     std::ifstream f(filename, std::ios::binary);
     if (!f.is_open()) throw std::ios_base::failure(std::string("Save file ") + filename + " was not successfully opened");
@@ -676,7 +719,9 @@ void HostIndex::load_graph(const char* filename)
         std::vector<uint64_t> degs(c);
         rd(degs.data(), 8 * c);
         for (uint64_t s = 0; s < c; s++) if (degs[s] > L.deg) {
-            // a file written with a larger Mmax than this object was constructed with
+            // a file written with a larger Mmax than this object was constructed with (64 is what the searches,
+            // host and device, are built for)
+            if (degs[s] > 64) throw std::domain_error(std::string(filename) + ": neighbour lists longer than 64 are not supported");
             L.deg = (uint32_t)degs[s];
         }
         L.reserve_nodes(c);

@@ -83,6 +83,8 @@ private:
     std::vector<std::unique_ptr<std::atomic_flag[]>> locks_;  // per layer, per slot (concurrent path)
     std::vector<size_t> lock_cap_;
 
+    void parse_graph_file(const char* filename);
+    void validate_loaded(const char* filename) const;
     int draw_level();
     template <bool MT> void insert_one(uint32_t id, const float* q, int level, const uint32_t* new_slots, Scratch& s);
     template <bool MT> void search_layer_one(int layer, const float* q, Scratch& s);

@@ -1079,6 +1079,34 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
     }
 }
 
+// Diagnostic: what the memory system delivers to the search kernel's row reads when nothing else is in the
+// way.  Every wavefront computes distances to `iters` batches of 32 uniformly random rows of the index's own
+// vector table with the search kernel's own loads and arithmetic (rows_distance: four lanes per row, 32 rows
+// in flight), but with no heaps, no visited set, no neighbour lists and no dependence of one batch on the
+// previous one.  Residency is set the way the search kernel's is, by the dynamic LDS size.
+__global__ __launch_bounds__(64) void gather_ceiling_kernel(DeviceGraph g, uint32_t iters, float* __restrict__ out)
+{
+    extern __shared__ __align__(16) uint32_t smem[];
+    float* qs = reinterpret_cast<float*>(smem);
+    const int lane = threadIdx.x;
+    const uint32_t qpad = (g.d + 63u) & ~63u;
+    for (uint32_t i = lane; i < qpad; i += 64) qs[i] = 0.0f;
+    LDS_SYNC();
+    const DistCtx dc = make_dist_ctx<false>(qs, g.d);
+    auto mix = [](uint32_t x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x; };
+    const uint32_t seed = blockIdx.x * 2654435761u + 12345u, r = (uint32_t)lane >> 2;
+    const bool act[2] = {true, true};
+    float acc = 0.0f;
+    for (uint32_t it = 0; it < iters; it++) {
+        uint32_t rid[2]; float dj[2];
+        rid[0] = __umulhi(mix(seed + it * 32u + 2u * r), g.n);
+        rid[1] = __umulhi(mix(seed + it * 32u + 2u * r + 1u), g.n);
+        rows_distance<false, 0, 2>(g, dc, rid, act, dj, lane);
+        acc += dj[0] + dj[1];
+    }
+    if (lane == 0) out[blockIdx.x] = acc;
+}
+
 // Rows as the caller has them (n x d, dense) -> stored form (n x row_stride, regrouped lines, zero padded).
 __global__ void store_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, uint32_t rows, uint32_t d, uint32_t row_stride)
 {
@@ -1143,6 +1171,8 @@ void DeviceIndex::release()
     if (d_spill) (void)hipFree(d_spill);
     d_spill = nullptr;
     if (h_fail) (void)hipHostFree(h_fail);
+    if (ev_done) (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(ev_done));
+    ev_done = nullptr;
     d_fail = nullptr; h_fail = nullptr; fail_cap = 0;
     version = ~0ull;
 }
@@ -1219,6 +1249,7 @@ void DeviceIndex::upload(const HostIndex& h, int dev)
     // set-up for the search calls: the pinned word the overflow count is read into, and this GPU's address of the
     // static scratch array (so that a search call itself never has to allocate or look anything up)
     if (!h_fail) HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_fail), 64, hipHostMallocDefault));
+    if (!ev_done) HIP_CHECK(hipEventCreateWithFlags(reinterpret_cast<hipEvent_t*>(&ev_done), hipEventDisableTiming));
     (void)noalloc_scratch_for(dev, true);
     version = h.version_;
     learn_flags = 0; learn_ef = 0; learn_visit = 0; learn_c = 0; learn_mean = 0;
@@ -1264,6 +1295,53 @@ void DeviceIndex::ensure_quantized(const HostIndex& h)
     HIP_CHECK(hipFree(tmp));
     g.q8_lo = lo; g.q8_inv_step = 1.0f / step;
     g.vectors_q8 = dq;
+}
+
+float DeviceIndex::gather_ceiling(uint32_t n_waves, uint32_t rows_per_wave, uint32_t lds_bytes, void* stream_v, uint64_t& bytes)
+{
+    if (device < 0) throw std::logic_error("gather_ceiling: index not on a device");
+    if (n_waves == 0 || rows_per_wave < 32) throw std::invalid_argument("gather_ceiling: need at least one wavefront and 32 rows each");
+    HIP_CHECK(hipSetDevice(device));
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+    const uint32_t iters = rows_per_wave / 32u;
+    const size_t min_lds = (size_t)((g.d + 63u) & ~63u) * 4;
+    size_t lds = std::max<size_t>(lds_bytes, min_lds);
+    if (lds > 65536) lds = 65536;
+    float* d_out = nullptr;
+    HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_out), (size_t)n_waves * 4));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    float ms = 0.0f;
+    try {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gather_ceiling_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
+        hipLaunchKernelGGL(gather_ceiling_kernel, dim3(n_waves), dim3(64), lds, stream, g, iters, d_out);       // warm-up
+        HIP_CHECK(hipEventRecord(e0, stream));
+        for (int rep = 0; rep < 3; rep++) hipLaunchKernelGGL(gather_ceiling_kernel, dim3(n_waves), dim3(64), lds, stream, g, iters, d_out);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipEventRecord(e1, stream));
+        HIP_CHECK(hipEventSynchronize(e1));
+        HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    } catch (...) {
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        (void)hipFree(d_out);
+        throw;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    HIP_CHECK(hipFree(d_out));
+    bytes = (uint64_t)n_waves * iters * 32u * (g.d & ~15u) * 4u;      // the bytes the search's counters would charge for these rows
+    return ms / 3.0f;
+}
+
+void DeviceIndex::last_launch(uint32_t& lds_bytes, uint32_t& resident_per_cu, uint32_t& visited_form) const
+{
+    lds_bytes = last_lds; visited_form = (uint32_t)last_form; resident_per_cu = 0;
+    if (!last_kernel) return;
+    HIP_CHECK(hipSetDevice(device));
+    int nb = 0;
+    if (last_lds <= 65536) HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, last_kernel, 64, last_lds));
+    else nb = (int)(163840 / last_lds);
+    resident_per_cu = (uint32_t)nb;
 }
 
 typedef void (*SearchKernel)(SearchArgs);
@@ -1354,7 +1432,7 @@ constexpr uint32_t kSpillTables = 1024, kSpillSlots = 16384;
 
 uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32_t out_k, uint32_t flags, uint32_t* d_ids,
                              float* d_dist, uint32_t* d_count, hnsw_amd_query_stats* d_stats, void* stream_v, bool sync_and_retry,
-                             bool no_alloc)
+                             bool no_alloc, const CopyBack* copy_back)
 {
     if (device < 0) throw std::logic_error("search: index not on a device");
     if (no_alloc && nq > kNoAllocMaxQueries)
@@ -1372,7 +1450,7 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
     if (no_alloc) {
         // this GPU's copy of the static scratch array, through the address looked up at upload (never the array's name)
         list_a = noalloc_scratch_for(device, false);
-        if (!list_a || !h_fail) throw std::logic_error("search (no-allocation entry point): the index was not set up on this device");
+        if (!list_a || !h_fail || !ev_done) throw std::logic_error("search (no-allocation entry point): the index was not set up on this device");
         list_b = list_a + (kNoAllocMaxQueries + kFailHeader);
     } else {
         if (fail_cap < nq + kFailHeader) {
@@ -1381,7 +1459,6 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
             HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_fail), ((size_t)nq + kFailHeader) * 4 * 2));
             fail_cap = nq + kFailHeader;
         }
-        if (!h_fail) HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_fail), 64, hipHostMallocDefault));
         list_a = d_fail;
         list_b = d_fail + fail_cap;
     }
@@ -1544,6 +1621,7 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
         if (timed) { HIP_CHECK(hipEventCreate(&ev0)); HIP_CHECK(hipEventCreate(&ev1)); HIP_CHECK(hipEventRecord(ev0, stream)); }
         hipLaunchKernelGGL(kern, dim3(a.nq_launch), dim3(64), lds, stream, a);
         HIP_CHECK(hipGetLastError());
+        if (tier == 0) { last_kernel = reinterpret_cast<const void*>(kern); last_lds = (uint32_t)lds; last_form = a.vis_rb == 0xFFFFFFFFu ? 0 : (a.vis_chunks ? 2 : 1); }
         if (timed) {
             HIP_CHECK(hipEventRecord(ev1, stream));
             HIP_CHECK(hipEventSynchronize(ev1));
@@ -1553,8 +1631,13 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
             (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
         }
         if (!sync_and_retry) return 0;
+        if (copy_back) HIP_CHECK(hipMemcpyAsync(copy_back->dst, copy_back->src, copy_back->bytes, hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipMemcpyAsync(h_fail, cur, 4 * kFailHeader, hipMemcpyDeviceToHost, stream));
-        HIP_CHECK(hipStreamSynchronize(stream));
+        // Wait for exactly this point of the stream (an event), not for the stream: the caller's stream is often the
+        // legacy default stream, whose synchronisation also covers whatever other threads of the process (a
+        // collective library's workers) keep adding to it or to streams it synchronises with.
+        HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_done), stream));
+        HIP_CHECK(hipEventSynchronize(reinterpret_cast<hipEvent_t>(ev_done)));
         const uint32_t nfail = h_fail[0];
         seen_visit = std::max(seen_visit, h_fail[1]);
         seen_c = std::max(seen_c, h_fail[2]);

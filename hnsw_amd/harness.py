@@ -13,6 +13,32 @@ import numpy as np
 REFERENCE_EF_SWEEP = [20, 30, 40, 50, 60, 70, 80, 90, 100, 120, 140, 160, 180, 200]
 
 
+def cpu_model() -> str:
+    """Model name of the host CPU (first "model name" line of /proc/cpuinfo), or "unknown"."""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def usable_cores() -> int:
+    """Host threads a CPU leg may use: the cores this process may run on, capped by OMP_NUM_THREADS when the
+    environment sets it (a shared machine hands every job a share of its cores that way)."""
+    import os
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    cap = os.environ.get("OMP_NUM_THREADS", "")
+    if cap.isdigit() and int(cap) > 0:
+        n = min(n, int(cap))
+    return max(1, n)
+
+
 def recall_at_k(ids: np.ndarray, gt: np.ndarray, k: int = 10) -> float:
     ids = np.asarray(ids)[:, :k]
     gt = np.asarray(gt)[:, :k]

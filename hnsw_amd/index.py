@@ -114,6 +114,20 @@ class HNSW:
                                                                    d_count or None, d_stats or None, stream or None, C.byref(retried)))
         return retried.value
 
+    def gather_ceiling(self, n_waves: int, rows_per_wave: int, lds_bytes_per_wave: int, stream: int = 0):
+        """(ms, bytes) of one launch of the row-gather probe on this index's vector table (see include/hnsw_amd.h)."""
+        ms, nbytes = C.c_float(0), C.c_uint64(0)
+        capi.check(capi.lib().hnsw_amd_gather_ceiling_device(self._h, n_waves, rows_per_wave, lds_bytes_per_wave, stream or None,
+                                                             C.byref(ms), C.byref(nbytes)))
+        return ms.value, nbytes.value
+
+    def last_launch_info(self) -> dict:
+        """Configuration of the last search call's first launch (see include/hnsw_amd.h)."""
+        v = [C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)]
+        capi.check(capi.lib().hnsw_amd_last_launch_info(self._h, *[C.byref(x) for x in v]))
+        return {"lds_bytes_per_query": v[0].value, "resident_queries_per_cu": v[1].value,
+                "visited_form": ("32-bit slots", "16-bit probing regions", "16-bit bucket regions")[min(v[2].value, 2)]}
+
     # -- flat graph exchange ---------------------------------------------------------------
     def import_flat(self, g: FlatGraph, vectors: np.ndarray) -> None:
         v = np.ascontiguousarray(vectors, dtype=np.float32)

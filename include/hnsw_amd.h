@@ -202,6 +202,27 @@ int hnsw_amd_merge_topk_device(const float* d_dist, const uint32_t* d_ids, const
 int hnsw_amd_get_info(hnsw_amd_index* h, int32_t* M, int32_t* Mmax, int32_t* Mmax0, int32_t* efConstruction,
                       uint32_t* vector_size, int32_t* max_node_count, int32_t* actual_node_count, uint32_t* nlayers);
 
+/* Measurement aid, no counterpart in the reference: the rate at which this GPU delivers the search kernel's row
+ * reads when nothing else is in the way.  n_waves wavefronts each compute distances to rows_per_wave (a multiple of
+ * 32) uniformly random rows of the index's own vector table with the search kernel's loads and arithmetic, but
+ * without heaps, visited set, neighbour lists or any dependence between batches; lds_bytes_per_wave sets how many
+ * wavefronts a CU holds, as the search's scratch does.  *ms = time of one launch, *bytes = what the search's
+ * counters would charge for those rows (4 * 16*floor(d/16) each); bytes / ms is the ceiling a search on this
+ * index can be compared with.  Waits for the stream. */
+int hnsw_amd_gather_ceiling_device(hnsw_amd_index* h, uint32_t n_waves, uint32_t rows_per_wave, uint32_t lds_bytes_per_wave, void* stream,
+                                   float* ms, uint64_t* bytes);
+
+/* Measurement aid, no counterpart in the reference: how the last search call's (first) launch was configured — on-chip
+ * scratch (LDS) bytes per query, how many queries a CU holds at once with that (what bounds a latency-bound
+ * search), and the form of the visited set (0: 32-bit slots, 1: 16-bit slots probed inside large regions,
+ * 2: 16-bit slots in small regions read whole, with overflow and spill tables).  Any pointer may be NULL. */
+int hnsw_amd_last_launch_info(hnsw_amd_index* h, uint32_t* lds_bytes_per_query, uint32_t* resident_queries_per_cu, uint32_t* visited_form);
+
+/* HNSW::vector_data_ — src/hnsw.h:231 (getNodeVector, :317): the index's host copy of the vectors,
+ * max_node_count x vector_size floats, row = node_order; NULL before init.  Owned by the index, read-only,
+ * valid until the next init / load_graph / import_flat / destroy. */
+int hnsw_amd_vector_data(hnsw_amd_index* h, const float** out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,6 +13,12 @@
 //
 //   ref_driver lquery <graph.savegraph> <M> <Mmax> <efC> <queries.bin> <nq> <results.out> <ef> [<ef>...]
 //   ref_driver ltime  <graph.savegraph> <M> <Mmax> <efC> <queries.bin> <nq> <ef> <seconds>
+//   ref_driver lprecision <graph.savegraph> <M> <Mmax> <efC> <queries.bin> <nq> <gt.bin> <gt_width> <ef> [<ef>...]
+//
+// "lprecision" is the reference driver's "Precision" figure (src/main.cpp:236-280) computed from the reference's
+// own aproximateKnn and W_: the first k+1 = 11 entries of W_ are kept (the loop there tests `c1++ >= k` after the
+// push), and every one of the first k = 10 ground-truth ids (gt.bin: nq x gt_width u32) found among them counts;
+// one JSON line per ef on stderr.
 //
 // "lquery"/"ltime" read the index with the reference's own HNSW::loadGraph (from a file in its
 // saveGraph format, e.g. one written by libhnsw_amd.so) instead of building it.
@@ -113,10 +119,36 @@ static int run_timing(HNSW& h, uint32_t d, const char* qpath, uint32_t nq, int e
     return 0;
 }
 
+static int run_precision(HNSW& h, uint32_t d, const char* qpath, uint32_t nq, const char* gtpath, uint32_t width,
+                         int argc, char** argv, int first_ef) {
+    const uint32_t k = 10;
+    if (width < k) { fprintf(stderr, "ground truth narrower than k\n"); return 2; }
+    auto q = read_floats(qpath, (size_t)nq * d);
+    std::vector<uint32_t> gt((size_t)nq * width);
+    FILE* f = fopen(gtpath, "rb");
+    if (!f || fread(gt.data(), 4, gt.size(), f) != gt.size()) { fprintf(stderr, "cannot read %s\n", gtpath); return 2; }
+    fclose(f);
+    for (int a = first_ef; a < argc; a++) {
+        const int ef = atoi(argv[a]);
+        double positive = 0;
+        for (uint32_t i = 0; i < nq; i++) {
+            h.aproximateKnn(&q[(size_t)i * d], (int)k, ef);
+            const size_t take = std::min<size_t>(h.W_.size(), k + 1);
+            for (uint32_t c = 0; c < k; c++) {
+                const uint32_t want = gt[(size_t)i * width + c];
+                for (size_t j = 0; j < take; j++)
+                    if (h.W_[j].node_order == want) { positive++; break; }
+            }
+        }
+        fprintf(stderr, "{\"ref_precision\": %.6f, \"nq\": %u, \"ef\": %d}\n", positive / ((double)nq * k), nq, ef);
+    }
+    return 0;
+}
+
 int main(int argc, char** argv) {
     if (argc < 9) { fprintf(stderr, "usage: see header of ref_driver.cpp\n"); return 2; }
     std::string mode = argv[1];
-    if (mode == "lquery" || mode == "ltime") {
+    if (mode == "lquery" || mode == "ltime" || mode == "lprecision") {
         HNSW h(atoi(argv[3]), atoi(argv[4]), atoi(argv[5]));
         fflush(stdout);
         FILE* devnull = freopen("/dev/null", "w", stdout);
@@ -124,6 +156,10 @@ int main(int argc, char** argv) {
         h.loadGraph(argv[2]);
         if (h.layers_.empty()) { fprintf(stderr, "loadGraph(%s) failed\n", argv[2]); return 2; }
         uint32_t nq = (uint32_t)atoll(argv[7]);
+        if (mode == "lprecision") {
+            if (argc < 11) return 2;
+            return run_precision(h, h.vector_size_, argv[6], nq, argv[8], (uint32_t)atoll(argv[9]), argc, argv, 10);
+        }
         if (mode == "lquery") {
             if (argc < 10) return 2;
             return run_queries(h, h.vector_size_, argv[6], nq, argv[8], argc, argv, 9);

@@ -33,12 +33,15 @@ class Golden:
         self.dist_mode = 1 if m["build"] == "scalar" else 0
 
 
-def assert_same_results(ids_a, dist_a, ids_b, dist_b, *, rtol=0.0, what=""):
+def assert_same_results(ids_a, dist_a, ids_b, dist_b, *, rtol=0.0, what="", last_group_open=True):
     """The parity rule: row by row, distances equal (bit for bit when rtol == 0, else to
     rtol relative), ids equal except for permutations inside a group of equal (rtol:
     near-equal) distances.  Rows are ascending; padding = id 0xFFFFFFFF / +inf.
-    When the rows were truncated (top-k of a longer list) the LAST tie group may hold
-    different members of the same distance, so its ids are not compared."""
+    last_group_open: the LAST tie group of a full row may hold different members of the same
+    distance, so its ids are not compared.  That is the case when the rows were truncated (top-k
+    of a longer list) and when W is kept as a sorted list (which of several entries tied with the
+    worst kept distance is dropped is then not the reference's choice).  Pass False when complete
+    lists of the std-heap mode are compared: every group must then agree."""
     ids_a, ids_b = np.asarray(ids_a), np.asarray(ids_b)
     dist_a, dist_b = np.asarray(dist_a), np.asarray(dist_b)
     assert ids_a.shape == ids_b.shape and dist_a.shape == dist_b.shape, what
@@ -60,7 +63,7 @@ def assert_same_results(ids_a, dist_a, ids_b, dist_b, *, rtol=0.0, what=""):
             while j < k and (da[j] == da[i] or (rtol > 0 and abs(da[j] - da[i]) <= rtol * abs(da[i]))):
                 j += 1
             ga, gb = sorted(ids_a[r, i:j].tolist()), sorted(ids_b[r, i:j].tolist())
-            last_group_truncated = (j == k) and np.isfinite(da[k - 1])
+            last_group_truncated = last_group_open and (j == k) and np.isfinite(da[k - 1])
             if ga != gb and not last_group_truncated:
                 raise AssertionError(f"{what}: row {r} ids differ outside a distance tie at [{i},{j}): {ids_a[r, i:j]} vs {ids_b[r, i:j]}")
             i = j

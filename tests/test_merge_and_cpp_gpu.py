@@ -48,6 +48,7 @@ def test_cpp_drop_in_class_runs_the_reference_style_driver(tmp_path):
     out = subprocess.run([exe, bp, str(n), str(d), qp, str(nq), gp, "100"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
     lines = [l for l in out.stdout.splitlines() if l.startswith("Precision:")]
+    print("\n".join(lines))                       # includes the time of one query per call (-s shows it)
     assert len(lines) == 14                      # the reference's sweep: 20..100 step 10, 120..200 step 20
     last = lines[-1]
     one, batched = float(last.split()[1].rstrip(",")), float(last.split("batched precision:")[1].split(",")[0])
@@ -59,6 +60,17 @@ def test_cpp_drop_in_class_runs_the_reference_style_driver(tmp_path):
     ids, _, _ = h.search_batch(q, 200, out_k=11)
     from hnsw_amd.harness import reference_precision
     assert abs(reference_precision(ids, gt, 10) - one) < 1e-9
+
+
+def test_cpp_class_serves_the_reference_public_members(tmp_path):
+    """stat_, visited_, vector_data_, layers_, print(int), file-call behaviour (src/hnsw.h:221-245) through the C++ class."""
+    exe = os.path.join(ROOT, "examples", "facade_check")
+    if not os.path.exists(exe):
+        pytest.fail("examples/facade_check is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    out = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:] + out.stdout[-2000:]
+    assert "facade ok" in out.stdout
+    assert "No. precise distance computations:" in out.stdout and "was not sucesfully opened" in out.stdout
 
 
 def test_cpp_hdf5_create_and_query(tmp_path):

@@ -42,3 +42,42 @@ def test_sharded_search_and_device_merge(S):
     assert_same_results(o_i.cpu().numpy().view(np.uint32), o_d.cpu().numpy(), eg, ed, what=f"{S} shards")
     gt = oracle.bruteforce(base, q, k, threads=8)
     assert recall_at_k(eg, gt, k) > 0.9
+
+
+def test_deep_shaped_eight_shards_through_ShardedHNSW_pieces():
+    """The DEEP-96 configuration's layout on one device: unit-norm 96-dim rows in 8 sub-graphs (built with the float
+    construction keys that configuration uses), searched with the reference's int32 keys, the 8 lists merged by the
+    device kernel from one gathered buffer laid out as the all-gather leaves it ([shard][dist|ids][nq][k]) — against
+    the per-shard CPU restatement + host merge."""
+    import torch
+    from hnsw_amd.sharded import ShardedHNSW
+    S, n, d, nq, ef, k = 8, 320_000, 96, 300, 30, 10
+    base = datagen.make("deep", n, seed=8)
+    q = datagen.make("deep", nq, seed=8, stream=1)
+    q_t = torch.from_numpy(q).cuda()
+    gathered = torch.empty((S, 2, nq, k), dtype=torch.int32, device="cuda")
+    exp_i, exp_d, keep = [], [], []
+    for s in range(S):
+        sh = ShardedHNSW(n, d, s, S, device=0)
+        sh.index.init(d, sh.hi - sh.lo)
+        sh.index.set_build_float_keys(True)
+        sh.index.insert_batch(base[sh.lo:sh.hi], threads=16)
+        keep.append(sh)
+        # the rank-local half of ShardedHNSW.search: the shard's own lists (world of one = no exchange)
+        one = ShardedHNSW.__new__(ShardedHNSW)
+        one.__dict__.update(sh.__dict__); one.world = 1
+        li, ld = one.search(q_t, ef, k)
+        gathered[s, 0].copy_(ld.view(torch.int32)); gathered[s, 1].copy_(li)
+        oi, od, _ = oracle.OracleIndex(sh.index.export_flat(), base[sh.lo:sh.hi]).search(q, ef, out_k=k, threads=8)
+        exp_i.append(oi); exp_d.append(od)
+    offs = keep[0].offsets
+    assert offs.tolist() == [s * n // S for s in range(S)]
+    o_i = torch.empty((nq, k), dtype=torch.int32, device="cuda")
+    o_d = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+    capi.check(capi.lib().hnsw_amd_merge_topk_device(gathered.data_ptr(), gathered.data_ptr() + 4 * nq * k, capi.u32(offs), S, nq, k, k,
+                                                     2 * nq * k, o_i.data_ptr(), o_d.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    eg, ed = merge_topk_numpy(np.stack(exp_d), np.stack(exp_i), offs, k)
+    assert_same_results(o_i.cpu().numpy().view(np.uint32), o_d.cpu().numpy(), eg, ed, what="deep, 8 shards")
+    gt = oracle.bruteforce(base, q, k, threads=8)
+    assert recall_at_k(eg, gt, k) > 0.95
