@@ -24,7 +24,13 @@ ap.add_argument("--keys", default="int32")
 ap.add_argument("--rows", default="f32", choices=["f32", "u8"])
 ap.add_argument("--build-keys", default="int32", choices=["int32", "float"])
 a = ap.parse_args()
-base = datagen.make(a.kind, a.n, seed=1)
+bcache = (a.cache + ".base.npy") if a.cache else ""
+if bcache and os.path.exists(bcache):
+    base = np.load(bcache)                       # (generating 10^7 rows takes longer than reading them back)
+else:
+    base = datagen.make(a.kind, a.n, seed=1)
+    if bcache and base.nbytes > (1 << 30):
+        np.save(bcache, base)
 q = datagen.make(a.kind, a.nq, seed=1, stream=1)
 h = HNSW(16, 16, 200)
 if a.cache and os.path.exists(a.cache):
@@ -44,6 +50,11 @@ for ef in [int(x) for x in a.ef.split(",")]:
     t = time.time()
     h.flags = capi.DIST_SSE | (capi.KEYS_FLOAT if a.keys == "float" else capi.KEYS_INT32) | (capi.ROWS_U8 if a.rows == "u8" else 0)
     ids, ds, cnt, st = h.search_batch(q, ef, out_k=10, stats=True)
+    if rep == a.reps - 1:
+        from hnsw_amd import harness
+        d_ = base.shape[1]
+        print("algorithmic_bytes_per_launch", int(harness.algorithmic_bytes(st, d_, d_ & ~15, 10, 1 if a.rows == "u8" else 4).sum()),
+              "launch", h.last_launch_info(), flush=True)
     print(f"rep {rep}: host wall {1e3*(time.time()-t):.2f} ms", flush=True)
   print("n_dist/q", st["n_dist"].mean(), "expansions/q", st["n_expand"].mean())
   for f in ("max_c", "n_visited0", "n_expand", "n_dist"):
