@@ -362,12 +362,17 @@ struct VisitedSet {
     uint32_t spill_slots; // bucket form: slots of a spill table in device memory
 };
 
-// `spill`: the query's spill table once it has one (bucket form only), else nullptr.
+// `spill`: the query's spill table once it has one (bucket form only), else nullptr.  The bucket form has its own
+// instantiations of the search kernel (BUCKET), so the probing forms do not carry its code and bookkeeping.
+template <bool BUCKET>
 __device__ __forceinline__ bool visited_insert(const VisitedSet& v, uint32_t* spill, uint32_t id, bool& overflow, bool& used_ovf)
 {
-    if (v.rb == 0xFFFFFFFFu) return visited_insert32(v.hash, v.size, id);
-    if (v.nchunk != 0u) return visited_insert_bucket(v.hash, v.regions, v.magic, v.nchunk, v.ovf, v.ovf_size, spill, v.spill_slots, id, used_ovf);
-    return visited_insert16(v.hash, v.rb, v.size >> v.rb, id, overflow);
+    if constexpr (BUCKET) {
+        return visited_insert_bucket(v.hash, v.regions, v.magic, v.nchunk, v.ovf, v.ovf_size, spill, v.spill_slots, id, used_ovf);
+    } else {
+        if (v.rb == 0xFFFFFFFFu) return visited_insert32(v.hash, v.size, id);
+        return visited_insert16(v.hash, v.rb, v.size >> v.rb, id, overflow);
+    }
 }
 
 // Diagnostic build only (-DHNSW_DIAG): the counters struct is overwritten with cycle sums
@@ -716,7 +721,8 @@ __device__ __forceinline__ uint32_t w_entry_dist(const uint32_t (&wd)[WR], uint3
 // ROWS = 2: from the quantised byte table (vectors_q8) with the query mapped to the same grid, so the
 //           search runs on approximate distances; its ef results are then re-scored with the exact
 //           float distance and sorted by it.
-template <bool SCALAR, int WR, int ROWS>
+// BUCKET: the visited set is in its bucket form (16-bit slots in small regions, overflow table, spill tables).
+template <bool SCALAR, int WR, int ROWS, bool BUCKET>
 __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
 {
     constexpr int NBUF = 2;
@@ -736,15 +742,15 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
     uint32_t* hash = reinterpret_cast<uint32_t*>(C + a.cap_c);
     const uint32_t H = a.hash_size, vis_rb = a.vis_rb;
     const uint32_t primary_words = vis_rb == 0xFFFFFFFFu ? H : H >> 1;
-    const uint32_t hash_words = primary_words + a.ovf_size;
+    const uint32_t hash_words = primary_words + (BUCKET ? a.ovf_size : 0u);
     const VisitedSet vs = {hash, H, vis_rb, a.vis_chunks, a.vis_regions, a.vis_magic, hash + primary_words, a.ovf_size, a.spill_slots};
     uint32_t* spill = nullptr;           // this query's spill table, once it needed one (layer 0 only)
     uint32_t n_spill = 0;
     const uint32_t spill_limit = a.spill_slots - (a.spill_slots >> 3);
     // the probing forms are kept at most 7/8 full; the bucket form fills its regions completely and keeps its
     // overflow table at most 7/8 full instead
-    const uint32_t visit_limit = a.vis_chunks ? 0xFFFFFFFFu : H - (H >> 3);
-    const uint32_t ovf_limit = a.vis_chunks ? a.ovf_size - (a.ovf_size >> 3) : 0xFFFFFFFFu;
+    const uint32_t visit_limit = BUCKET ? 0xFFFFFFFFu : H - (H >> 3);
+    const uint32_t ovf_limit = BUCKET ? a.ovf_size - (a.ovf_size >> 3) : 0xFFFFFFFFu;
     uint32_t n_ovf = 0;
     bool vis_ovf = false, used_ovf = false;
     const DistCtx dc = make_dist_ctx<SCALAR>(qs, a.g.d);
@@ -774,8 +780,8 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
     const int L = (int)a.g.nlayers - 1;
     uint32_t cur_slot = a.g.top_ep_slot, cur_id = a.g.top_ep_order;
     float cur_dist;
-    if (lane == 0) visited_insert(vs, nullptr, cur_id, vis_ovf, used_ovf);
-    n_ovf += __ballot(lane == 0 && used_ovf) ? 1u : 0u;
+    if (lane == 0) visited_insert<BUCKET>(vs, nullptr, cur_id, vis_ovf, used_ovf);
+    if (BUCKET) n_ovf += __ballot(lane == 0 && used_ovf) ? 1u : 0u;
     {
         uint32_t rid[RM::kSub]; bool act[RM::kSub]; float dj[RM::kSub];
 #pragma unroll
@@ -794,7 +800,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
         bool change = true;
         while (change && !fail) {
             change = false;
-            if (nvis + 64 > visit_limit || n_ovf + 64 > ovf_limit) { fail = 1; break; }
+            if (nvis + 64 > visit_limit || (BUCKET && n_ovf + 64 > ovf_limit)) { fail = 1; break; }
             st.n_sweeps++;
             // The sweep covers the whole list of the node current at its start; the running best moves
             // only on a strict improvement, i.e. to the first minimum of the list.
@@ -804,9 +810,9 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
                 if (b0 + mrow < a.g.degu) { my_order = a.g.up_adj_order[rowi + b0 + mrow]; my_slot = a.g.up_adj_slot[rowi + b0 + mrow]; }
                 const bool live = my_order != kEmpty;
                 used_ovf = false;
-                const bool fresh = live && visited_insert(vs, nullptr, my_order, vis_ovf, used_ovf);
-                if (__ballot(vis_ovf)) { fail = 1; break; }
-                n_ovf += (uint32_t)__popcll(__ballot(fresh && used_ovf));
+                const bool fresh = live && visited_insert<BUCKET>(vs, nullptr, my_order, vis_ovf, used_ovf);
+                if (!BUCKET && __ballot(vis_ovf)) { fail = 1; break; }
+                if (BUCKET) n_ovf += (uint32_t)__popcll(__ballot(fresh && used_ovf));
                 const uint32_t m = (uint32_t)__popcll(__ballot(fresh));
                 st.sum_degu += (uint32_t)__popcll(__ballot(live));
                 st.n_dist += m; nvis += m;
@@ -847,9 +853,9 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
         if (lane == 0) {
             if (WR == 0) W[0] = make_uint2(__float_as_uint(cur_dist), cur_id);
             C[0] = make_uint2(float_keys ? __float_as_uint(cur_dist) : (uint32_t)trunc_key(cur_dist), cur_id);
-            visited_insert(vs, nullptr, cur_id, vis_ovf, used_ovf);
+            visited_insert<BUCKET>(vs, nullptr, cur_id, vis_ovf, used_ovf);
         }
-        n_ovf = __ballot(lane == 0 && used_ovf) ? 1u : 0u;
+        if (BUCKET) n_ovf = __ballot(lane == 0 && used_ovf) ? 1u : 0u;
 #pragma unroll
         for (int w = 0; w < (WR > 0 ? WR : 1); w++) { wd[w] = 0; wi[w] = 0; }
         if (WR > 0 && lane == 0) { wd[0] = __float_as_uint(cur_dist); wi[0] = cur_id; }
@@ -878,7 +884,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
             for (uint32_t b0 = 0;;) {
                 DIAG_STAMP(t1b);
                 if (nvis + 64 > visit_limit) { fail = 1; break; }
-                if (n_ovf + 64 > ovf_limit) {
+                if (BUCKET && n_ovf + 64 > ovf_limit) {
                     // the overflow table is at its limit: continue in a spill table in device memory, taken from the
                     // launch's pool (the queries that get here are few; one that finds the pool empty is re-run)
                     if (!spill) {
@@ -894,9 +900,9 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
                 const bool live = my != kEmpty;
                 const uint32_t nlive = (uint32_t)__popcll(__ballot(live));
                 used_ovf = false;
-                const bool fresh = live && visited_insert(vs, spill, my, vis_ovf, used_ovf);
-                if (__ballot(vis_ovf)) { fail = 1; break; }
-                {
+                const bool fresh = live && visited_insert<BUCKET>(vs, spill, my, vis_ovf, used_ovf);
+                if (!BUCKET && __ballot(vis_ovf)) { fail = 1; break; }
+                if (BUCKET) {
                     const uint32_t added = (uint32_t)__popcll(__ballot(fresh && used_ovf));
                     if (spill) n_spill += added; else n_ovf += added;
                 }
@@ -1346,23 +1352,29 @@ void DeviceIndex::last_launch(uint32_t& lds_bytes, uint32_t& resident_per_cu, ui
 
 typedef void (*SearchKernel)(SearchArgs);
 
-template <bool SCALAR, int ROWS>
+template <bool SCALAR, int ROWS, bool BUCKET>
 static SearchKernel pick_wr(int wr)
 {
     switch (wr) {
-        case 0: return hnsw_search_kernel<SCALAR, 0, ROWS>;
-        case 1: return hnsw_search_kernel<SCALAR, 1, ROWS>;
-        case 2: return hnsw_search_kernel<SCALAR, 2, ROWS>;
-        default: return hnsw_search_kernel<SCALAR, 4, ROWS>;
+        case 0: return hnsw_search_kernel<SCALAR, 0, ROWS, BUCKET>;
+        case 1: return hnsw_search_kernel<SCALAR, 1, ROWS, BUCKET>;
+        case 2: return hnsw_search_kernel<SCALAR, 2, ROWS, BUCKET>;
+        default: return hnsw_search_kernel<SCALAR, 4, ROWS, BUCKET>;
     }
 }
 
-static SearchKernel pick_kernel(bool scalar, int wr, int rows)
+template <bool BUCKET>
+static SearchKernel pick_rows(bool scalar, int wr, int rows)
 {
-    if (scalar) return pick_wr<true, 0>(wr);
-    if (rows == 1) return pick_wr<false, 1>(wr);
-    if (rows == 2) return pick_wr<false, 2>(wr);
-    return pick_wr<false, 0>(wr);
+    if (scalar) return pick_wr<true, 0, BUCKET>(wr);
+    if (rows == 1) return pick_wr<false, 1, BUCKET>(wr);
+    if (rows == 2) return pick_wr<false, 2, BUCKET>(wr);
+    return pick_wr<false, 0, BUCKET>(wr);
+}
+
+static SearchKernel pick_kernel(bool scalar, int wr, int rows, bool bucket)
+{
+    return bucket ? pick_rows<true>(scalar, wr, rows) : pick_rows<false>(scalar, wr, rows);
 }
 
 constexpr size_t kLdsPerCu = 163840;     // gfx950: 160 KB
@@ -1526,7 +1538,8 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
         if (!std_heap && a.cap_w > a.cap_c) throw std::logic_error("search: W does not fit the space it borrows for the final sort");
         size_t lds = search_lds_bytes(a, std_heap);
         const int wr = std_heap ? 0 : (ef <= 64 ? 1 : (ef <= 128 ? 2 : 4));
-        const SearchKernel kern = pick_kernel(scalar, wr, u8 ? 1 : (q8 ? 2 : 0));
+        const SearchKernel kern_p = pick_kernel(scalar, wr, u8 ? 1 : (q8 ? 2 : 0), false);     // probing forms
+        const SearchKernel kern_b = pick_kernel(scalar, wr, u8 ? 1 : (q8 ? 2 : 0), true);      // bucket form
         // LDS a query may use without lowering residency: the float-row kernels need 110-118 VGPRs, i.e. 4 waves per
         // SIMD = 16 one-wave workgroups per CU (the byte-row kernels could run 24, measured no faster than 16), and a
         // batch of fewer than 16 queries per CU needs even fewer slots (bounded, so that clearing the tables stays cheap).
@@ -1539,9 +1552,9 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
             // HNSW_AMD_VISITED32 / HNSW_AMD_VISITED16 / HNSW_AMD_VISITEDB force one form.
             const bool force16 = getenv("HNSW_AMD_VISITED16") != nullptr, forceb = getenv("HNSW_AMD_VISITEDB") != nullptr;
             if (!getenv("HNSW_AMD_VISITED32") && (force16 || forceb || lds > budget)) {
-                auto occupancy = [&](size_t bytes) {
+                auto occupancy = [&](size_t bytes, bool bucket = false) {
                     int occ = 0;
-                    if (bytes <= 65536) HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kern), 64, bytes));
+                    if (bytes <= 65536) HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(bucket ? kern_b : kern_p), 64, bytes));
                     else occ = (int)(kLdsPerCu / bytes);
                     return occ;
                 };
@@ -1571,7 +1584,7 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
                     if (spill_ok && ldsb != ~(size_t)0 && ldsb <= lds16) {
                         SearchArgs bs = a;
                         const size_t ldss = bucket_args(want_bulk0, shape_bulk, bs);
-                        if (ldss != ~(size_t)0 && (force_bulk || occupancy(ldss) > occupancy(ldsb))) {
+                        if (ldss != ~(size_t)0 && (force_bulk || occupancy(ldss, true) > occupancy(ldsb, true))) {
                             if (!d_spill) HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_spill), (size_t)kSpillTables * kSpillSlots * 4));
                             bs.spill_pool = d_spill; bs.spill_tables = spill_tables; bs.spill_slots = kSpillSlots;
                             bb = bs; ldsb = ldss;
@@ -1581,7 +1594,7 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
                 const bool use_b = ldsb < lds16;
                 const size_t ldsn = use_b ? ldsb : lds16;
                 if (ldsn != ~(size_t)0) {
-                    const int occ32 = occupancy(lds), occn = occupancy(ldsn);
+                    const int occ32 = occupancy(lds), occn = occupancy(ldsn, use_b);
                     // (beyond 16 queries per CU the cheaper 32-bit probe wins: measured on the byte-row kernel, 16 -> 20)
                     if (force16 || forceb || (occn > occ32 && occ32 < 16)) { a = use_b ? bb : b16; lds = ldsn; }
                 }
@@ -1600,6 +1613,7 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
             throw std::length_error("search: " + std::to_string(a.nq_launch) +
                                     " queries outgrew the largest on-chip scratch configuration (ef too large for LDS?)");
         }
+        const SearchKernel kern = a.vis_chunks ? kern_b : kern_p;
         a.fail_count = cur; a.fail_list = cur + kFailHeader;
         HIP_CHECK(hipMemsetAsync(cur, 0, 4 * kFailHeader, stream));
         if (lds > 32768)
