@@ -709,6 +709,54 @@ __device__ __forceinline__ uint32_t w_entry_dist(const uint32_t (&wd)[WR], uint3
     return v;
 }
 
+// Maximum of an unsigned value over the 64 lanes (same DPP steps as wave_min_u32).
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t x)
+{
+    uint32_t y;
+    y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0xB1, 0xF, 0xF, false); x = x > y ? x : y;
+    y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x4E, 0xF, 0xF, false); x = x > y ? x : y;
+    y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x141, 0xF, 0xF, false); x = x > y ? x : y;
+    y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x140, 0xF, 0xF, false); x = x > y ? x : y;
+    y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x142, 0xA, 0xF, false); x = x > y ? x : y;
+    y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x143, 0xC, 0xF, false); x = x > y ? x : y;
+    return __builtin_amdgcn_readlane(x, 63);
+}
+
+// W over more than one register per lane (ef > 64) is kept as an UNORDERED set: keeping several registers sorted
+// costs a shift through all of them per admitted neighbour, while the search itself only ever needs the largest
+// distance f and the size.  A full W admits by overwriting an entry that holds the largest distance (its bits
+// are f's) and taking the maximum again; the order is made once, when the results are written.  Slots past the
+// current size hold distance bits 0, which never win a maximum.
+template <int WR>
+__device__ __forceinline__ void w_set_append(uint32_t (&wd)[WR], uint32_t (&wi)[WR], uint32_t slot, uint32_t db, uint32_t id, int lane)
+{
+#pragma unroll
+    for (int w = 0; w < WR; w++)
+        if (64u * w + (uint32_t)lane == slot) { wd[w] = db; wi[w] = id; }
+}
+
+// Replaces one entry whose distance bits are `fb` (the current maximum; W holds `n` entries) and returns the new maximum.
+template <int WR>
+__device__ __forceinline__ uint32_t w_set_replace_max(uint32_t (&wd)[WR], uint32_t (&wi)[WR], uint32_t n, uint32_t fb, uint32_t db, uint32_t id, int lane)
+{
+    bool done = false;
+#pragma unroll
+    for (int w = 0; w < WR; w++) {
+        if (done) continue;                                   // wave-uniform
+        const uint32_t left = n > 64u * w ? n - 64u * w : 0u;
+        const unsigned long long valid = left >= 64u ? ~0ull : (1ull << left) - 1ull;
+        const unsigned long long b = __ballot(wd[w] == fb) & valid;
+        if (b) {
+            if (lane == __builtin_ctzll(b)) { wd[w] = db; wi[w] = id; }
+            done = true;
+        }
+    }
+    uint32_t m = wd[0];
+#pragma unroll
+    for (int w = 1; w < WR; w++) m = m > wd[w] ? m : wd[w];
+    return wave_max_u32(m);
+}
+
 // WR = 0: the result list W is the libstdc++ max-heap in LDS, maintained exactly as the
 //         reference does (so even the choice among several equally distant worst entries
 //         is the reference's).
@@ -938,8 +986,12 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
                                 const uint2 ce = make_uint2(__builtin_amdgcn_readlane(keym, j), id);
                                 nC++;
                                 const uint2 anc = heap_push_read<COrder>(C, nC, lane);      // in flight during the insert into W
-                                w_sorted_insert<(WR > 0 ? WR : 1)>(wd, wi, ef, db, id, lane);
-                                f = __uint_as_float(w_entry_dist<(WR > 0 ? WR : 1)>(wd, ef - 1));
+                                if constexpr (WR >= 2) {
+                                    f = __uint_as_float(w_set_replace_max<(WR > 0 ? WR : 1)>(wd, wi, ef, __float_as_uint(f), db, id, lane));
+                                } else {
+                                    w_sorted_insert<(WR > 0 ? WR : 1)>(wd, wi, ef, db, id, lane);
+                                    f = __uint_as_float(w_entry_dist<(WR > 0 ? WR : 1)>(wd, ef - 1));
+                                }
                                 heap_push_finish<COrder>(C, nC, ce, anc, lane);
                                 LDS_SYNC();
                             }
@@ -957,9 +1009,19 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
                             nC++;
                             if (WR > 0) {
                                 heap_push_wave<COrder>(C, nC, ce, lane);
-                                w_sorted_insert<(WR > 0 ? WR : 1)>(wd, wi, nW, we.x, we.y, lane);
-                                if (nW < ef) nW++;
-                                f = __uint_as_float(w_entry_dist<(WR > 0 ? WR : 1)>(wd, nW - 1));
+                                if constexpr (WR >= 2) {
+                                    if (nW < ef) {
+                                        w_set_append<(WR > 0 ? WR : 1)>(wd, wi, nW, we.x, we.y, lane);
+                                        nW++;
+                                        f = dist > f ? dist : f;          // (the largest distance in W, as W_.front() of the reference's heap)
+                                    } else {
+                                        f = __uint_as_float(w_set_replace_max<(WR > 0 ? WR : 1)>(wd, wi, ef, __float_as_uint(f), we.x, we.y, lane));
+                                    }
+                                } else {
+                                    w_sorted_insert<(WR > 0 ? WR : 1)>(wd, wi, nW, we.x, we.y, lane);
+                                    if (nW < ef) nW++;
+                                    f = __uint_as_float(w_entry_dist<(WR > 0 ? WR : 1)>(wd, nW - 1));
+                                }
                                 LDS_SYNC();
                             } else {
                                 nW++;
@@ -1004,7 +1066,43 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
 
     // ---- sort W ascending by (distance, id) (src/hnsw.cpp:447) and write the first out_k ----
     LDS_SYNC();
-    if (WR > 0) {
+    // Only entries that can rank below out_k take part in the sort: those not farther than the out_k-th smallest
+    // distance `dk`.  (The quantised-row mode re-scores everything first, so it sorts everything.)
+    uint32_t nsort = nW;
+    if constexpr (WR >= 2 && ROWS != 2) {
+        // W is an unordered set in registers: find dk by taking minima (counting ties) until out_k entries are
+        // covered, then write the entries up to dk to LDS back to back
+        uint32_t dk = 0xFFFFFFFFu;
+        if (a.out_k < nW) {
+            uint32_t covered = 0, t = 0;
+            bool first = true;
+            while (covered < a.out_k) {
+                uint32_t m = 0xFFFFFFFFu;
+#pragma unroll
+                for (int w = 0; w < WR; w++) {
+                    const bool in = (uint32_t)(w * 64 + lane) < nW && (first || wd[w] > t);
+                    m = in && wd[w] < m ? wd[w] : m;
+                }
+                t = wave_min_u32(m);
+                first = false;
+#pragma unroll
+                for (int w = 0; w < WR; w++)
+                    covered += (uint32_t)__popcll(__ballot((uint32_t)(w * 64 + lane) < nW && wd[w] == t));
+            }
+            dk = t;
+        }
+        uint32_t base = 0;
+#pragma unroll
+        for (int w = 0; w < WR; w++) {
+            const bool sel = (uint32_t)(w * 64 + lane) < nW && wd[w] <= dk;
+            const unsigned long long b = __ballot(sel);
+            const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+            if (sel) W[base + before] = make_uint2(wd[w], wi[w]);
+            base += (uint32_t)__popcll(b);
+        }
+        nsort = base;
+        LDS_SYNC();
+    } else if (WR > 0) {
 #pragma unroll
         for (int w = 0; w < WR; w++)
             if ((uint32_t)(w * 64 + lane) < nW) W[w * 64 + lane] = make_uint2(wd[w], wi[w]);
@@ -1031,10 +1129,8 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
         }
         LDS_SYNC();
     }
-    // Only entries that can rank below out_k take part.  The register form wrote W in ascending order of
-    // distance, so those are the first `nsort`: the entries not farther than the out_k-th.
-    uint32_t nsort = nW;
-    if (WR > 0 && ROWS != 2 && a.out_k < nW) {
+    // The one-register form wrote W in ascending order of distance, so the entries up to dk are the first ones.
+    if (WR == 1 && ROWS != 2 && a.out_k < nW) {
         const uint32_t dk = w_entry_dist<(WR > 0 ? WR : 1)>(wd, a.out_k - 1);
         nsort = 0;
 #pragma unroll
