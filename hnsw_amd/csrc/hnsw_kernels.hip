@@ -84,6 +84,26 @@ __device__ __forceinline__ int32_t trunc_key(float f)
 // wait: only the compiler has to be kept from reordering the accesses.
 #define LDS_SYNC() asm volatile("" ::: "memory")
 
+// Loads that are known to read device memory say so (address space 1).  A pointer taken from a kernel-argument
+// struct is a generic pointer to the compiler, and a generic ("flat") load may turn out to read LDS: it then counts
+// against the LDS counter as well as the memory counter and may return out of order with either kind, so every
+// wait for ANY LDS read or memory load issued around it becomes a wait for all of them.  With explicit global
+// loads, a neighbour list requested before the heap is repaired really is in flight during the repair, and the
+// rows of a batch really arrive while earlier ones are being consumed.
+typedef float gf4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t gu4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t gload_u32(const uint32_t* p) { return *(const __attribute__((address_space(1))) uint32_t*)p; }
+__device__ __forceinline__ float4 gload_f4(const float* p)
+{
+    const gf4_t v = *(const __attribute__((address_space(1))) gf4_t*)p;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ uint4 gload_u4(const uint8_t* p)
+{
+    const gu4_t v = *(const __attribute__((address_space(1))) gu4_t*)p;
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ float rflf(float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); }
 
@@ -456,7 +476,7 @@ __device__ __forceinline__ void issue_item(const float* p, uint32_t nld, float4 
 {
 #pragma unroll
     for (int t = 0; t < 8; t++)
-        if (FULL || (uint32_t)t < nld) v[t] = *reinterpret_cast<const float4*>(p + (SCALAR ? 4 * t : 32 * (t >> 1) + 4 * (t & 1)));
+        if (FULL || (uint32_t)t < nld) v[t] = gload_f4(p + (SCALAR ? 4 * t : 32 * (t >> 1) + 4 * (t & 1)));
 }
 
 // SSE order, lane j of the row's quad: p / qp point at this lane's 8 floats of the item's first line.
@@ -479,8 +499,8 @@ __device__ __forceinline__ void consume_item_sse(const float* qp, uint32_t nld, 
 // consecutive elements of the lane's chain (16 dims of the row).
 __device__ __forceinline__ void issue_item_u8(const uint8_t* p, uint4 (&v)[2])
 {
-    v[0] = *reinterpret_cast<const uint4*>(p);
-    v[1] = *reinterpret_cast<const uint4*>(p + 16);
+    v[0] = gload_u4(p);
+    v[1] = gload_u4(p + 16);
 }
 
 __device__ __forceinline__ uint32_t u4_get(const uint4& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
@@ -532,9 +552,8 @@ __device__ __forceinline__ void consume_item_scalar(const float* qp, uint32_t e0
 
 // Distances from the query to up to kSub rows per lane group: row[s] points at the stored row
 // (already offset to this lane's part), act[s] says whether the lane takes part.  out[s] is
-// valid in every lane of the row's group.  Called by all 64 lanes.  The loads of NBUF = 2 items are
-// in flight at any time; with rows of up to 128 dims that is both sub-batches of an SSE batch.  (Four
-// items in flight were measured on 960-dim rows: more registers, no gain.)
+// valid in every lane of the row's group.  Called by all 64 lanes.  The loads of NBUF items are in
+// flight at any time; with rows of up to 128 dims NBUF = 2 is both sub-batches of an SSE batch.
 template <bool SCALAR, int NBUF>
 __device__ __forceinline__ void batch_distance(const DistCtx& c, const float* const (&row)[RowMap<SCALAR>::kSub],
                                                const bool (&act)[RowMap<SCALAR>::kSub], float (&out)[RowMap<SCALAR>::kSub], int lane)
@@ -563,6 +582,9 @@ __device__ __forceinline__ void batch_distance(const DistCtx& c, const float* co
         }
         if (s) acc[RM::kSub - 1] = a; else acc[0] = a;
     };
+    // (A pipeline in which every step issues the same number of loads, so that the wait before a piece is used
+    // need not cover the loads issued after it, was measured on 960-dim rows: slower, by the loads it adds to keep
+    // the count fixed.)
 #pragma unroll
     for (int b = 0; b < NBUF; b++)
         if ((uint32_t)b < total) issue(buf[b], b);
@@ -770,10 +792,12 @@ __device__ __forceinline__ uint32_t w_set_replace_max(uint32_t (&wd)[WR], uint32
 //           search runs on approximate distances; its ef results are then re-scored with the exact
 //           float distance and sorted by it.
 // BUCKET: the visited set is in its bucket form (16-bit slots in small regions, overflow table, spill tables).
-template <bool SCALAR, int WR, int ROWS, bool BUCKET>
+// NBUF: row pieces (8 x 16-byte loads per lane each) in flight during a distance batch.  2 is all a 128-dim row
+//       has to offer; the deep form (6) is for wide rows in a batch too small to fill the chip, where a CU holds
+//       only a few queries, registers are plentiful and nothing but a longer queue of loads hides the memory latency.
+template <bool SCALAR, int WR, int ROWS, bool BUCKET, int NBUF>
 __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
 {
-    constexpr int NBUF = 2;
     typedef RowMap<SCALAR> RM;
     typedef BatchLanes<SCALAR> BL;
     extern __shared__ __align__(16) uint32_t smem[];
@@ -844,7 +868,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
     // ---- greedy descent through layers L..1; visited shared by all of them
     //      (src/hnsw.cpp:403-412, 676-717) ----
     for (int l = L; l > 0 && !fail; l--) {
-        const uint32_t base = a.g.up_off[l];
+        const uint32_t base = gload_u32(&a.g.up_off[l]);
         bool change = true;
         while (change && !fail) {
             change = false;
@@ -855,7 +879,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
             const size_t rowi = (size_t)(base + cur_slot) * a.g.degu;
             for (uint32_t b0 = 0; b0 < a.g.degu; b0 += RM::kRowsPerBatch) {
                 uint32_t my_order = kEmpty, my_slot = kEmpty;           // merged form
-                if (b0 + mrow < a.g.degu) { my_order = a.g.up_adj_order[rowi + b0 + mrow]; my_slot = a.g.up_adj_slot[rowi + b0 + mrow]; }
+                if (b0 + mrow < a.g.degu) { my_order = gload_u32(&a.g.up_adj_order[rowi + b0 + mrow]); my_slot = gload_u32(&a.g.up_adj_slot[rowi + b0 + mrow]); }
                 const bool live = my_order != kEmpty;
                 used_ovf = false;
                 const bool fresh = live && visited_insert<BUCKET>(vs, nullptr, my_order, vis_ovf, used_ovf);
@@ -884,7 +908,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
                 }
             }
         }
-        if (!fail) cur_slot = a.g.up_down[base + cur_slot];      // changeLayer, src/hnsw.h:575-587
+        if (!fail) cur_slot = gload_u32(&a.g.up_down[base + cur_slot]);      // changeLayer, src/hnsw.h:575-587
     }
     st.n_visited_up = nvis;
     DIAG_STAMP(t_up_end);
@@ -917,7 +941,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
                 const uint2 c = C[0];
                 ckey = rfl(c.x); cid = rfl(c.y);
                 // the candidate's neighbour list is requested now and arrives while the heap is repaired
-                if (mrow < a.g.deg0) my = a.g.adj0[(size_t)cid * a.g.deg0 + mrow];
+                if (mrow < a.g.deg0) my = gload_u32(&a.g.adj0[(size_t)cid * a.g.deg0 + mrow]);
                 if (nC > 1) {
                     heap_pop_wave<COrder>(C, nC, lane);
                 }
@@ -1048,7 +1072,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
                 // the live entries of a list are a prefix: a batch with a gap was the last one
                 b0 += RM::kRowsPerBatch;
                 if (b0 >= a.g.deg0 || nlive < (uint32_t)RM::kRowsPerBatch) break;
-                my = b0 + mrow < a.g.deg0 ? a.g.adj0[(size_t)cid * a.g.deg0 + b0 + mrow] : kEmpty;
+                my = b0 + mrow < a.g.deg0 ? gload_u32(&a.g.adj0[(size_t)cid * a.g.deg0 + b0 + mrow]) : kEmpty;
             }
         }
     }
@@ -1448,28 +1472,30 @@ void DeviceIndex::last_launch(uint32_t& lds_bytes, uint32_t& resident_per_cu, ui
 
 typedef void (*SearchKernel)(SearchArgs);
 
-template <bool SCALAR, int ROWS, bool BUCKET>
+template <bool SCALAR, int ROWS, bool BUCKET, int NBUF>
 static SearchKernel pick_wr(int wr)
 {
     switch (wr) {
-        case 0: return hnsw_search_kernel<SCALAR, 0, ROWS, BUCKET>;
-        case 1: return hnsw_search_kernel<SCALAR, 1, ROWS, BUCKET>;
-        case 2: return hnsw_search_kernel<SCALAR, 2, ROWS, BUCKET>;
-        default: return hnsw_search_kernel<SCALAR, 4, ROWS, BUCKET>;
+        case 0: return hnsw_search_kernel<SCALAR, 0, ROWS, BUCKET, NBUF>;
+        case 1: return hnsw_search_kernel<SCALAR, 1, ROWS, BUCKET, NBUF>;
+        case 2: return hnsw_search_kernel<SCALAR, 2, ROWS, BUCKET, NBUF>;
+        default: return hnsw_search_kernel<SCALAR, 4, ROWS, BUCKET, NBUF>;
     }
 }
 
 template <bool BUCKET>
 static SearchKernel pick_rows(bool scalar, int wr, int rows)
 {
-    if (scalar) return pick_wr<true, 0, BUCKET>(wr);
-    if (rows == 1) return pick_wr<false, 1, BUCKET>(wr);
-    if (rows == 2) return pick_wr<false, 2, BUCKET>(wr);
-    return pick_wr<false, 0, BUCKET>(wr);
+    if (scalar) return pick_wr<true, 0, BUCKET, 2>(wr);
+    if (rows == 1) return pick_wr<false, 1, BUCKET, 2>(wr);
+    if (rows == 2) return pick_wr<false, 2, BUCKET, 2>(wr);
+    return pick_wr<false, 0, BUCKET, 2>(wr);
 }
 
-static SearchKernel pick_kernel(bool scalar, int wr, int rows, bool bucket)
+// deep: the float-row, probing-form kernel with six row pieces in flight (see hnsw_search_kernel)
+static SearchKernel pick_kernel(bool scalar, int wr, int rows, bool bucket, bool deep = false)
 {
+    if (deep && !scalar && rows == 0 && !bucket) return pick_wr<false, 0, false, 6>(wr);
     return bucket ? pick_rows<true>(scalar, wr, rows) : pick_rows<false>(scalar, wr, rows);
 }
 
@@ -1634,7 +1660,9 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
         if (!std_heap && a.cap_w > a.cap_c) throw std::logic_error("search: W does not fit the space it borrows for the final sort");
         size_t lds = search_lds_bytes(a, std_heap);
         const int wr = std_heap ? 0 : (ef <= 64 ? 1 : (ef <= 128 ? 2 : 4));
-        const SearchKernel kern_p = pick_kernel(scalar, wr, u8 ? 1 : (q8 ? 2 : 0), false);     // probing forms
+        // wide rows in a batch that leaves most of the chip idle: more loads in flight per query
+        const bool deep_rows = g.d > 256 && (uint64_t)a.nq_launch <= 8ull * (uint64_t)num_cus && !getenv("HNSW_AMD_NO_DEEP_ROWS");
+        const SearchKernel kern_p = pick_kernel(scalar, wr, u8 ? 1 : (q8 ? 2 : 0), false, deep_rows);     // probing forms
         const SearchKernel kern_b = pick_kernel(scalar, wr, u8 ? 1 : (q8 ? 2 : 0), true);      // bucket form
         // LDS a query may use without lowering residency: the float-row kernels need 110-118 VGPRs, i.e. 4 waves per
         // SIMD = 16 one-wave workgroups per CU (the byte-row kernels could run 24, measured no faster than 16), and a
