@@ -82,8 +82,8 @@ class ShardedHNSW:
         else:
             li, ld = local_search(q_t, ef, k)
             loc_i.copy_(li); loc_d.copy_(ld)
-        if self.world == 1:
-            return loc_i, loc_d
+        if self.world == 1 and self.group is None:
+            return loc_i, loc_d            # (with a process group the exchange runs even for a world of one: same code path)
         if loc.is_cuda and dist.get_backend(self.group) != "nccl":
             # a host-side backend (gloo: rehearsals of the multi-GPU path on one GPU): exchange host copies
             loc_h = loc.cpu()

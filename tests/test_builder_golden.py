@@ -124,3 +124,26 @@ def test_float_build_keys_change_nothing_on_integer_data_and_work_on_unit_norm_d
     h2.insert_batch(base, threads=8)
     ids, _, _ = oracle.OracleIndex(h2.export_flat(), base).search(q, 64, out_k=10, key_mode=oracle.KEYS_FLOAT, threads=4)
     assert recall_at_k(ids, gt, 10) > 0.95
+
+
+def test_concurrent_build_leaves_no_more_weakly_linked_nodes_than_the_sequential_one():
+    """A concurrent insert can descend through a node another thread has only just added (no neighbours there yet)
+    and link itself thinly.  Counted here: nodes of low degree after a threaded build against the sequential
+    (reference-exact) build of the same rows."""
+    from hnsw_amd import datagen
+    base = datagen.make("sift", 20000, seed=3)
+
+    def weak(threads):
+        h = HNSW(16, 16, 200)
+        h.init(128, len(base))
+        h.insert_batch(base, threads=threads)
+        g = h.export_flat()
+        up = [g.up_cnt[g.up_off[l]:g.up_off[l + 1]] for l in range(1, g.nlayers)]
+        return int((g.cnt0 < 8).sum()), int((g.cnt0 < 2).sum()), sum(int((u <= 1).sum()) for u in up if len(u) > 16), float(g.cnt0.mean())
+
+    s8, s2, sup, smean = weak(1)
+    c8, c2, cup, cmean = weak(8)
+    assert c8 <= 1.25 * s8 + 20, (c8, s8)            # layer-0 nodes with fewer than M/2 neighbours
+    assert c2 <= s2 + 3, (c2, s2)                    # nearly isolated layer-0 nodes
+    assert cup <= sup + 3, (cup, sup)                # upper-layer nodes with at most one neighbour
+    assert abs(cmean - smean) < 0.2

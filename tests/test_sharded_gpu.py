@@ -81,3 +81,34 @@ def test_deep_shaped_eight_shards_through_ShardedHNSW_pieces():
     assert_same_results(o_i.cpu().numpy().view(np.uint32), o_d.cpu().numpy(), eg, ed, what="deep, 8 shards")
     gt = oracle.bruteforce(base, q, k, threads=8)
     assert recall_at_k(eg, gt, k) > 0.95
+
+
+def test_exchange_over_rccl_with_a_world_of_one():
+    """The exchange step as the multi-GPU runs take it — torch.distributed backend "nccl" (= RCCL), all_gather_into_tensor of
+    the packed [dist | ids] buffer on the device, then the device merge reading the gathered buffer with its stride — on the one
+    GPU this box has: a process group of a single rank.  Against the oracle on the same shard."""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    from hnsw_amd.sharded import ShardedHNSW
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        n, d, nq, ef, k = 20000, 96, 257, 30, 10
+        base = datagen.make("deep", n, seed=12)
+        q = datagen.make("deep", nq, seed=12, stream=1)
+        sh = ShardedHNSW(n, d, 0, 1, device=0, group=dist.group.WORLD)
+        sh.build(base, threads=16)
+        ids, ds = sh.search(torch.from_numpy(q).cuda(), ef, k)
+        torch.cuda.synchronize()
+        oi, od, _ = oracle.OracleIndex(sh.index.export_flat(), base).search(q, ef, out_k=k)
+        assert_same_results(ids.cpu().numpy().view(np.uint32), ds.cpu().numpy(), oi, od, what="one rank over RCCL")
+    finally:
+        dist.destroy_process_group()
