@@ -22,6 +22,7 @@ KEYS_INT32, KEYS_FLOAT = 0, 2
 W_STD_HEAP = 4
 ROWS_U8 = 8
 ROWS_Q8 = 16
+METRIC_IP = 32
 
 _u32p = C.POINTER(C.c_uint32)
 _f32p = C.POINTER(C.c_float)

@@ -480,13 +480,19 @@ __device__ __forceinline__ void issue_item(const float* p, uint32_t nld, float4 
 }
 
 // SSE order, lane j of the row's quad: p / qp point at this lane's 8 floats of the item's first line.
-template <bool FULL>
+// IP: the chain accumulates the products q_i * x_i instead of the squared differences (inner-product metric).
+template <bool FULL, bool IP>
 __device__ __forceinline__ void consume_item_sse(const float* qp, uint32_t nld, const float4 (&v)[8], float& a)
 {
 #pragma unroll
     for (int t = 0; t < 8; t++)
         if (FULL || (uint32_t)t < nld) {
             const float4 q = *reinterpret_cast<const float4*>(qp + 32 * (t >> 1) + 4 * (t & 1));
+            if constexpr (IP) {
+                a = __builtin_fmaf(v[t].x, q.x, a); a = __builtin_fmaf(v[t].y, q.y, a);
+                a = __builtin_fmaf(v[t].z, q.z, a); a = __builtin_fmaf(v[t].w, q.w, a);
+                continue;
+            }
             // the differences two at a time (packed f32 subtract: same IEEE result per element); the chain itself is serial
             typedef float f2 __attribute__((ext_vector_type(2)));
             const f2 dlo = f2{v[t].x, v[t].y} - f2{q.x, q.y}, dhi = f2{v[t].z, v[t].w} - f2{q.z, q.w};
@@ -554,7 +560,7 @@ __device__ __forceinline__ void consume_item_scalar(const float* qp, uint32_t e0
 // (already offset to this lane's part), act[s] says whether the lane takes part.  out[s] is
 // valid in every lane of the row's group.  Called by all 64 lanes.  The loads of NBUF items are in
 // flight at any time; with rows of up to 128 dims NBUF = 2 is both sub-batches of an SSE batch.
-template <bool SCALAR, int NBUF>
+template <bool SCALAR, int NBUF, bool IP = false>
 __device__ __forceinline__ void batch_distance(const DistCtx& c, const float* const (&row)[RowMap<SCALAR>::kSub],
                                                const bool (&act)[RowMap<SCALAR>::kSub], float (&out)[RowMap<SCALAR>::kSub], int lane)
 {
@@ -578,7 +584,7 @@ __device__ __forceinline__ void batch_distance(const DistCtx& c, const float* co
         float a = s ? acc[RM::kSub - 1] : acc[0];
         if (s ? act[RM::kSub - 1] : act[0]) {
             if (SCALAR) { if (g < nf) consume_item_scalar<true>(qp, 0, 0, v, a); else consume_item_scalar<false>(qp, g * RM::kItemFloats, c.d4, v, a); }
-            else { if (g < nf) consume_item_sse<true>(qp, 0, v, a); else consume_item_sse<false>(qp, tl, v, a); }
+            else { if (g < nf) consume_item_sse<true, IP>(qp, 0, v, a); else consume_item_sse<false, IP>(qp, tl, v, a); }
         }
         if (s) acc[RM::kSub - 1] = a; else acc[0] = a;
     };
@@ -605,7 +611,10 @@ __device__ __forceinline__ void batch_distance(const DistCtx& c, const float* co
         const float a1 = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, ai, 0x55, 0xF, 0xF, false));
         const float a2 = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, ai, 0xAA, 0xF, 0xF, false));
         const float a3 = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, ai, 0xFF, 0xF, 0xF, false));
-        out[s] = ((a0 + a1) + a2) + a3;
+        const float sum = ((a0 + a1) + a2) + a3;
+        // inner-product metric: 1 - q.x, held at 0 from below (the heaps and W order distances by their bit patterns);
+        // on unit vectors this is half the squared L2 distance
+        out[s] = IP ? __builtin_fmaxf(1.0f - sum, 0.0f) : sum;
     }
 }
 
@@ -648,7 +657,7 @@ __device__ __forceinline__ void batch_distance_u8(const DistCtx& c, const uint8_
 }
 
 // Distances to the rows `id[s]` (sub-batch s; act[s]: the lane's row takes part), from the float or the byte table.
-template <bool SCALAR, int ROWS, int NBUF = 2>
+template <bool SCALAR, int ROWS, int NBUF = 2, bool IP = false>
 __device__ __forceinline__ void rows_distance(const DeviceGraph& g, const DistCtx& c, const uint32_t (&id)[RowMap<SCALAR>::kSub],
                                               const bool (&act)[RowMap<SCALAR>::kSub], float (&out)[RowMap<SCALAR>::kSub], int lane)
 {
@@ -664,7 +673,7 @@ __device__ __forceinline__ void rows_distance(const DeviceGraph& g, const DistCt
         const float* row[RM::kSub];
 #pragma unroll
         for (int s = 0; s < RM::kSub; s++) row[s] = g.vectors + (size_t)id[s] * g.row_stride + (SCALAR ? 0u : 8u * (lane & 3));
-        batch_distance<SCALAR, NBUF>(c, row, act, out, lane);
+        batch_distance<SCALAR, NBUF, IP>(c, row, act, out, lane);
     }
 }
 
@@ -795,7 +804,8 @@ __device__ __forceinline__ uint32_t w_set_replace_max(uint32_t (&wd)[WR], uint32
 // NBUF: row pieces (8 x 16-byte loads per lane each) in flight during a distance batch.  2 is all a 128-dim row
 //       has to offer; the deep form (6) is for wide rows in a batch too small to fill the chip, where a CU holds
 //       only a few queries, registers are plentiful and nothing but a longer queue of loads hides the memory latency.
-template <bool SCALAR, int WR, int ROWS, bool BUCKET, int NBUF>
+// IP: inner-product metric (distance 1 - q.x) instead of squared L2; float rows, SSE order only.
+template <bool SCALAR, int WR, int ROWS, bool BUCKET, int NBUF, bool IP>
 __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
 {
     typedef RowMap<SCALAR> RM;
@@ -858,7 +868,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
         uint32_t rid[RM::kSub]; bool act[RM::kSub]; float dj[RM::kSub];
 #pragma unroll
         for (int s = 0; s < RM::kSub; s++) { rid[s] = cur_id; act[s] = s == 0 && lane < RM::kLanesPerRow; }
-        rows_distance<SCALAR, ROWS, NBUF>(a.g, dc, rid, act, dj, lane);
+        rows_distance<SCALAR, ROWS, NBUF, IP>(a.g, dc, rid, act, dj, lane);
         cur_dist = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(dj[0]), 0));
     }
     st.n_dist = 1;
@@ -893,7 +903,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
                 uint32_t rid[RM::kSub]; bool act[RM::kSub]; float dj[RM::kSub];
 #pragma unroll
                 for (int s = 0; s < RM::kSub; s++) { rid[s] = BL::spread(my_order, s); act[s] = BL::spread((uint32_t)fresh, s) != 0; }
-                rows_distance<SCALAR, ROWS, NBUF>(a.g, dc, rid, act, dj, lane);
+                rows_distance<SCALAR, ROWS, NBUF, IP>(a.g, dc, rid, act, dj, lane);
                 const float dm = (!SCALAR && (lane & 3) == 1) ? dj[RM::kSub - 1] : dj[0];      // merged form
                 const bool mine = fresh && dm == dm;
                 const uint32_t key = mine ? __float_as_uint(dm) : 0x7F800000u;     // non-negative floats order as their bit patterns
@@ -987,7 +997,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
                     uint32_t rid[RM::kSub]; bool act[RM::kSub]; float dj[RM::kSub];
 #pragma unroll
                     for (int s = 0; s < RM::kSub; s++) { rid[s] = BL::spread(my, s); act[s] = BL::spread((uint32_t)fresh, s) != 0; }
-                    rows_distance<SCALAR, ROWS, NBUF>(a.g, dc, rid, act, dj, lane);
+                    rows_distance<SCALAR, ROWS, NBUF, IP>(a.g, dc, rid, act, dj, lane);
                     const float dm = (!SCALAR && (lane & 3) == 1) ? dj[RM::kSub - 1] : dj[0];      // merged form
                     DIAG_STAMP(t3);
                     DIAG_ADD(cy_dist, t2, t3);
@@ -1472,20 +1482,21 @@ void DeviceIndex::last_launch(uint32_t& lds_bytes, uint32_t& resident_per_cu, ui
 
 typedef void (*SearchKernel)(SearchArgs);
 
-template <bool SCALAR, int ROWS, bool BUCKET, int NBUF>
+template <bool SCALAR, int ROWS, bool BUCKET, int NBUF, bool IP = false>
 static SearchKernel pick_wr(int wr)
 {
     switch (wr) {
-        case 0: return hnsw_search_kernel<SCALAR, 0, ROWS, BUCKET, NBUF>;
-        case 1: return hnsw_search_kernel<SCALAR, 1, ROWS, BUCKET, NBUF>;
-        case 2: return hnsw_search_kernel<SCALAR, 2, ROWS, BUCKET, NBUF>;
-        default: return hnsw_search_kernel<SCALAR, 4, ROWS, BUCKET, NBUF>;
+        case 0: return hnsw_search_kernel<SCALAR, 0, ROWS, BUCKET, NBUF, IP>;
+        case 1: return hnsw_search_kernel<SCALAR, 1, ROWS, BUCKET, NBUF, IP>;
+        case 2: return hnsw_search_kernel<SCALAR, 2, ROWS, BUCKET, NBUF, IP>;
+        default: return hnsw_search_kernel<SCALAR, 4, ROWS, BUCKET, NBUF, IP>;
     }
 }
 
 template <bool BUCKET>
-static SearchKernel pick_rows(bool scalar, int wr, int rows)
+static SearchKernel pick_rows(bool scalar, int wr, int rows, bool ip)
 {
+    if (ip) return pick_wr<false, 0, BUCKET, 2, true>(wr);
     if (scalar) return pick_wr<true, 0, BUCKET, 2>(wr);
     if (rows == 1) return pick_wr<false, 1, BUCKET, 2>(wr);
     if (rows == 2) return pick_wr<false, 2, BUCKET, 2>(wr);
@@ -1493,10 +1504,10 @@ static SearchKernel pick_rows(bool scalar, int wr, int rows)
 }
 
 // deep: the float-row, probing-form kernel with six row pieces in flight (see hnsw_search_kernel)
-static SearchKernel pick_kernel(bool scalar, int wr, int rows, bool bucket, bool deep = false)
+static SearchKernel pick_kernel(bool scalar, int wr, int rows, bool bucket, bool ip, bool deep = false)
 {
-    if (deep && !scalar && rows == 0 && !bucket) return pick_wr<false, 0, false, 6>(wr);
-    return bucket ? pick_rows<true>(scalar, wr, rows) : pick_rows<false>(scalar, wr, rows);
+    if (deep && !scalar && rows == 0 && !bucket && !ip) return pick_wr<false, 0, false, 6>(wr);
+    return bucket ? pick_rows<true>(scalar, wr, rows, ip) : pick_rows<false>(scalar, wr, rows, ip);
 }
 
 constexpr size_t kLdsPerCu = 163840;     // gfx950: 160 KB
@@ -1608,6 +1619,9 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
     if (u8 && !g.vectors_u8)
         throw std::invalid_argument("search: HNSW_AMD_ROWS_U8 needs base vectors whose values are all integers in 0..255");
     if (q8 && !g.vectors_q8) throw std::logic_error("search: the quantised table was not built");
+    const bool ip = (flags & HNSW_AMD_METRIC_IP) != 0;
+    if (ip && (u8 || q8 || (flags & HNSW_AMD_DIST_SCALAR)))
+        throw std::invalid_argument("search: HNSW_AMD_METRIC_IP goes with float rows and HNSW_AMD_DIST_SSE only");
     a.qpad = (u8 || q8) ? ((g.d + 127u) & ~127u) : ((g.d + 63u) & ~63u);
     a.out_ids = d_ids; a.out_dist = d_dist; a.out_count = d_count; a.stats = d_stats;
     const bool scalar = (flags & HNSW_AMD_DIST_SCALAR) != 0;
@@ -1662,8 +1676,8 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
         const int wr = std_heap ? 0 : (ef <= 64 ? 1 : (ef <= 128 ? 2 : 4));
         // wide rows in a batch that leaves most of the chip idle: more loads in flight per query
         const bool deep_rows = g.d > 256 && (uint64_t)a.nq_launch <= 8ull * (uint64_t)num_cus && !getenv("HNSW_AMD_NO_DEEP_ROWS");
-        const SearchKernel kern_p = pick_kernel(scalar, wr, u8 ? 1 : (q8 ? 2 : 0), false, deep_rows);     // probing forms
-        const SearchKernel kern_b = pick_kernel(scalar, wr, u8 ? 1 : (q8 ? 2 : 0), true);      // bucket form
+        const SearchKernel kern_p = pick_kernel(scalar, wr, u8 ? 1 : (q8 ? 2 : 0), false, ip, deep_rows);     // probing forms
+        const SearchKernel kern_b = pick_kernel(scalar, wr, u8 ? 1 : (q8 ? 2 : 0), true, ip);      // bucket form
         // LDS a query may use without lowering residency: the float-row kernels need 110-118 VGPRs, i.e. 4 waves per
         // SIMD = 16 one-wave workgroups per CU (the byte-row kernels could run 24, measured no faster than 16), and a
         // batch of fewer than 16 queries per CU needs even fewer slots (bounded, so that clearing the tables stays cheap).

@@ -58,6 +58,14 @@ enum {
                                      distance and sorted by it.  4x fewer bytes gathered; an approximation of the
                                      reference's search, not a reproduction (the idea the reference left disabled,
                                      see HNSW_AMD_ROWS_U8).  With HNSW_AMD_DIST_SSE only. */
+    HNSW_AMD_METRIC_IP = 32,      /* No counterpart in the reference, which has squared L2 only (src/hnsw.h:334-400).  Distance of
+                                     the search = max(0, 1 - sum q_i x_i) over the first 16*floor(d/16) dims (same four fused
+                                     multiply-add chains and final addition order as HNSW_AMD_DIST_SSE): the inner-product /
+                                     angular metric for unit-length vectors, where it is half the squared L2 distance and ranks
+                                     the same.  The index is built with squared L2 as always.  With float rows and
+                                     HNSW_AMD_DIST_SSE only.  Under HNSW_AMD_KEYS_INT32 every key is 0 or 1: use
+                                     HNSW_AMD_KEYS_FLOAT.  Checked against the CPU restatement; parity with the reference is
+                                     unpinned because the reference cannot compute it. */
     HNSW_AMD_W_STD_HEAP = 4       /* keep the result list W_ as the libstdc++ binary heap the reference keeps
                                      (src/hnsw.cpp:770-775), so that when several entries tie for the worst
                                      distance the one dropped is the reference's choice as well.  Default (flag

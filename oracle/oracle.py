@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
-DIST_SSE, DIST_SCALAR = 0, 1
+DIST_SSE, DIST_SCALAR, DIST_IP = 0, 1, 2      # DIST_IP: this library's inner-product metric (no reference counterpart)
 KEYS_INT32, KEYS_FLOAT = 0, 1
 
 _u32p = C.POINTER(C.c_uint32)

@@ -123,3 +123,42 @@ def test_odd_dimensions_match_oracle(d):
             assert_same_results(ids, dist, oi, od, what=f"d={d} flags={flags} ef={ef}")
             for field in st.dtype.names:
                 assert np.array_equal(st[field], ost[field]), f"d={d} flags={flags} ef={ef}: counter {field}"
+
+
+@pytest.mark.parametrize("keys", ["float", "int32"])
+def test_inner_product_metric_against_the_cpu_restatement(keys):
+    """HNSW_AMD_METRIC_IP: distance max(0, 1 - q.x) in the SSE loop's summation order.  PARITY UNPINNED: the reference has
+    squared L2 only (src/hnsw.h:334-400), so the checker is the CPU restatement's own statement of the same formula —
+    results, distances bit for bit and all counters.  On unit vectors the metric is half the squared L2 distance, so
+    the results must also be (nearly) the L2 search's and recall against the exact L2 neighbours must be as good."""
+    from hnsw_amd import capi, datagen
+    from oracle import oracle
+    from tests.helpers import assert_same_results, recall_at_k
+    base = datagen.make("deep", 50000, seed=31)
+    q = datagen.make("deep", 300, seed=31, stream=1)
+    h = HNSW(16, 16, 200)
+    h.init(96, len(base))
+    h.set_build_float_keys(True)
+    h.insert_batch(base, threads=16)
+    idx = oracle.OracleIndex(h.export_flat(), base)
+    kflag, kmode = (capi.KEYS_FLOAT, oracle.KEYS_FLOAT) if keys == "float" else (capi.KEYS_INT32, oracle.KEYS_INT32)
+    gt = oracle.bruteforce(base, q, 10, threads=8)
+    for ef in (16, 64, 100):
+        ids, dist, cnt, st = h.search_batch(q, ef, flags=capi.DIST_SSE | capi.METRIC_IP | kflag, stats=True)
+        oi, od, oc, ost = idx.search(q, ef, dist_mode=oracle.DIST_IP, key_mode=kmode, stats=True)
+        assert np.array_equal(cnt, oc)
+        assert_same_results(ids, dist, oi, od, what=f"inner product, ef={ef}, keys={keys}")
+        for f in st.dtype.names:
+            assert np.array_equal(st[f], ost[f]), (ef, f)
+        assert (dist >= 0).all() and (dist <= 2.0001).all()
+        if ef >= 64:
+            assert recall_at_k(ids, gt, 10) > 0.97
+    if keys == "float":
+        # (under int32 keys all keys are 0 or 1 and the order of expansion is the heap's tie order, which differs between the metrics)
+        l2_ids, l2_d, _ = h.search_batch(q, 64, flags=capi.DIST_SSE | kflag)
+        ip_ids, ip_d, _ = h.search_batch(q, 64, flags=capi.DIST_SSE | capi.METRIC_IP | kflag)
+        assert np.allclose(2.0 * ip_d[:, :10], l2_d[:, :10], rtol=0, atol=2e-6)
+        assert (ip_ids[:, :10] == l2_ids[:, :10]).mean() > 0.95
+    with pytest.raises(capi.HnswAmdError) as e:
+        h.search_batch(q, 16, flags=capi.DIST_SCALAR | capi.METRIC_IP)
+    assert e.value.code == capi.E_ARG
