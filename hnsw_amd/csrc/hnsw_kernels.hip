@@ -235,6 +235,16 @@ __device__ __forceinline__ uint2 heap_pop_wave(uint2* a, uint32_t n /* size befo
     return root;
 }
 
+// Checking build only (-DHNSW_CHECKS, `make -C hnsw_amd/csrc checks`): invariants of the lock-step visited sets are
+// re-read from LDS and a violation is counted in a device word that the launcher turns into an error.  The shipped
+// library contains none of this.
+#ifdef HNSW_CHECKS
+__device__ uint32_t g_check_failures = 0;
+#define HNSW_CHECK_THAT(cond) do { if (!(cond)) atomicAdd(&g_check_failures, 1u); } while (0)
+#else
+#define HNSW_CHECK_THAT(cond) do { } while (0)
+#endif
+
 // Exact visited set: open addressing, linear probing, one LDS compare-and-swap per probe.
 // Returns true when `id` was not in the set (and now is).
 // The table has `size` slots, any number (no power of two needed): the start slot is the
@@ -288,6 +298,9 @@ __device__ __forceinline__ bool visited_insert16(uint32_t* hash, uint32_t rb, ui
         word = advance ? next : word;
     } while (!hit && probes < pairs);
     overflow = overflow || !hit;
+    // a tag counted as this lane's own insertion sits where the lane wrote it
+    HNSW_CHECK_THAT(!fresh || (wrote_at != 0xFFFFFFFFu && h16[wrote_at] == (uint16_t)tag));
+    HNSW_CHECK_THAT(tag < 0xFFFFu);
     return fresh;
 }
 
@@ -356,6 +369,10 @@ __device__ __forceinline__ bool visited_insert_bucket(uint32_t* hash, uint32_t r
         count = (hdr + 1u) & 0xFFFFu;
     }
     used_ovf = full;
+    HNSW_CHECK_THAT(tag < 0xFFFFu && region < regions);
+    // the region's count never passes its usable slots, and every slot below it holds a tag
+    HNSW_CHECK_THAT((((uint32_t)h16[S - 1u] + 1u) & 0xFFFFu) <= S - 1u);
+    HNSW_CHECK_THAT(!(fresh || hit) || [&] { bool there = false; for (uint32_t i = 0; i + 1u < S; i++) there = there || h16[i] == (uint16_t)tag; return there; }());
     if (!full) return fresh;
     if (!spill) return visited_insert32(ovf, ovf_size, id);
     // the overflow table is closed: look only
@@ -1790,6 +1807,13 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
         // collective library's workers) keep adding to it or to streams it synchronises with.
         HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_done), stream));
         HIP_CHECK(hipEventSynchronize(reinterpret_cast<hipEvent_t>(ev_done)));
+#ifdef HNSW_CHECKS
+        {
+            uint32_t bad = 0;
+            HIP_CHECK(hipMemcpyFromSymbol(&bad, HIP_SYMBOL(g_check_failures), 4));
+            if (bad) throw std::logic_error("search (checking build): " + std::to_string(bad) + " invariant violations in the visited set");
+        }
+#endif
         const uint32_t nfail = h_fail[0];
         seen_visit = std::max(seen_visit, h_fail[1]);
         seen_c = std::max(seen_c, h_fail[2]);

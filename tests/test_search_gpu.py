@@ -236,3 +236,24 @@ def test_bucket_form_spills_to_device_memory(monkeypatch, tables):
         assert_same_results(ids, dist, oi, od, what=f"deep ef={ef} spill")
         for f in st.dtype.names:
             assert np.array_equal(st[f], ost[f]), (ef, f)
+
+
+def test_visited_set_invariants_under_the_checking_build():
+    """The 16-bit forms of the visited set rely on lock-step execution instead of atomics.  A checking build of the
+    library (make -C hnsw_amd/csrc checks; never loaded by the package itself) re-reads, after every insertion, that a
+    tag counted as the lane's own sits where the lane wrote it, that tags and region counts stay in range and that a
+    found tag is in its region, and turns any violation into an error.  The form-equality and spill tests run against it
+    in a child process (the library is chosen when the binding is first loaded)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "hnsw_amd", "libhnsw_amd_checks.so")
+    if not os.path.exists(lib):
+        pytest.fail("hnsw_amd/libhnsw_amd_checks.so is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    env = dict(os.environ, HNSW_AMD_LIB=lib)
+    out = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "--timeout", "300", "--timeout-method", "thread", __file__, "-k",
+                          "all_forms_of_the_visited_set or spills_to_device_memory or bucket_form_on_unit_norm"],
+                         capture_output=True, text=True, env=env, cwd=root, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert "passed" in out.stdout
