@@ -45,6 +45,7 @@ struct SearchArgs {
     float* out_dist;          // nq x out_k
     uint32_t* out_count;      // nq or nullptr
     hnsw_amd_query_stats* stats;   // nq or nullptr
+    uint32_t known_visit, known_c;   // largest visited set / heap room the launcher already knows of: only queries beyond report
     uint32_t* fail_count;     // device words: [0] number of queries whose scratch overflowed in this launch,
                               // [1] largest visited set, [2] most room the candidate heap was asked for, among the queries
                               // that finished, [3] spill tables handed out, [4] sum of the visited counts / 16 and [5] number of a sample of them
@@ -68,7 +69,10 @@ public:
     uint32_t* d_fail = nullptr;       // [0] = count, [1..] list
     uint32_t fail_cap = 0;
     uint32_t* h_fail = nullptr;       // pinned host mirror of the list header
-    void* ev_done = nullptr;          // hipEvent_t the search calls wait on (created at upload)
+    struct OccupancyNote { const void* kernel; size_t bytes; int blocks; };
+    std::vector<OccupancyNote> occupancy_notes;   // resident workgroups per CU the runtime reported, by kernel and LDS size
+    uint32_t learn_age = 0;           // batches since the sizes were learned
+    int dev_max_lds = 0, dev_num_cus = 0;   // device attributes, looked up once
     uint32_t* d_spill = nullptr;      // pool of spill tables (bucket form of the visited set), allocated on first need
     // largest visited set and candidate heap the queries of earlier batches reached, and the ef / flags they were
     // observed at: later batches are sized from them

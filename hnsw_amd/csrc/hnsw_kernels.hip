@@ -23,6 +23,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -84,26 +85,10 @@ __device__ __forceinline__ int32_t trunc_key(float f)
 // wait: only the compiler has to be kept from reordering the accesses.
 #define LDS_SYNC() asm volatile("" ::: "memory")
 
-// Loads that are known to read device memory say so (address space 1).  A pointer taken from a kernel-argument
-// struct is a generic pointer to the compiler, and a generic ("flat") load may turn out to read LDS: it then counts
-// against the LDS counter as well as the memory counter and may return out of order with either kind, so every
-// wait for ANY LDS read or memory load issued around it becomes a wait for all of them.  With explicit global
-// loads, a neighbour list requested before the heap is repaired really is in flight during the repair, and the
-// rows of a batch really arrive while earlier ones are being consumed.
-typedef float gf4_t __attribute__((ext_vector_type(4)));
-typedef uint32_t gu4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ uint32_t gload_u32(const uint32_t* p) { return *(const __attribute__((address_space(1))) uint32_t*)p; }
-__device__ __forceinline__ float4 gload_f4(const float* p)
-{
-    const gf4_t v = *(const __attribute__((address_space(1))) gf4_t*)p;
-    return make_float4(v.x, v.y, v.z, v.w);
-}
-__device__ __forceinline__ uint4 gload_u4(const uint8_t* p)
-{
-    const gu4_t v = *(const __attribute__((address_space(1))) gu4_t*)p;
-    return make_uint4(v.x, v.y, v.z, v.w);
-}
-
+// (Loads of lists and rows are left as generic loads on purpose.  Giving them the device address space lets the
+// compiler wait for exactly the loads it needs, but also lets it move them past the LDS work they were placed in
+// front of, and the overlap written into the code — a neighbour list requested before the heap is repaired, rows
+// requested before the query is read — is lost: measured 40 % slower on the one-lane-per-row path and 9 % at ef=20.)
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ float rflf(float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); }
 
@@ -493,7 +478,7 @@ __device__ __forceinline__ void issue_item(const float* p, uint32_t nld, float4 
 {
 #pragma unroll
     for (int t = 0; t < 8; t++)
-        if (FULL || (uint32_t)t < nld) v[t] = gload_f4(p + (SCALAR ? 4 * t : 32 * (t >> 1) + 4 * (t & 1)));
+        if (FULL || (uint32_t)t < nld) v[t] = *reinterpret_cast<const float4*>(p + (SCALAR ? 4 * t : 32 * (t >> 1) + 4 * (t & 1)));
 }
 
 // SSE order, lane j of the row's quad: p / qp point at this lane's 8 floats of the item's first line.
@@ -522,8 +507,8 @@ __device__ __forceinline__ void consume_item_sse(const float* qp, uint32_t nld, 
 // consecutive elements of the lane's chain (16 dims of the row).
 __device__ __forceinline__ void issue_item_u8(const uint8_t* p, uint4 (&v)[2])
 {
-    v[0] = gload_u4(p);
-    v[1] = gload_u4(p + 16);
+    v[0] = *reinterpret_cast<const uint4*>(p);
+    v[1] = *reinterpret_cast<const uint4*>(p + 16);
 }
 
 __device__ __forceinline__ uint32_t u4_get(const uint4& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
@@ -822,8 +807,9 @@ __device__ __forceinline__ uint32_t w_set_replace_max(uint32_t (&wd)[WR], uint32
 //       has to offer; the deep form (6) is for wide rows in a batch too small to fill the chip, where a CU holds
 //       only a few queries, registers are plentiful and nothing but a longer queue of loads hides the memory latency.
 // IP: inner-product metric (distance 1 - q.x) instead of squared L2; float rows, SSE order only.
+// (Except for the deep-prefetch form the kernels are held to 128 registers: four wavefronts per SIMD = 16 queries per CU.)
 template <bool SCALAR, int WR, int ROWS, bool BUCKET, int NBUF, bool IP>
-__global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBUF == 2 ? 4 : 1))) void hnsw_search_kernel(SearchArgs a)
 {
     typedef RowMap<SCALAR> RM;
     typedef BatchLanes<SCALAR> BL;
@@ -895,7 +881,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
     // ---- greedy descent through layers L..1; visited shared by all of them
     //      (src/hnsw.cpp:403-412, 676-717) ----
     for (int l = L; l > 0 && !fail; l--) {
-        const uint32_t base = gload_u32(&a.g.up_off[l]);
+        const uint32_t base = a.g.up_off[l];
         bool change = true;
         while (change && !fail) {
             change = false;
@@ -906,7 +892,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
             const size_t rowi = (size_t)(base + cur_slot) * a.g.degu;
             for (uint32_t b0 = 0; b0 < a.g.degu; b0 += RM::kRowsPerBatch) {
                 uint32_t my_order = kEmpty, my_slot = kEmpty;           // merged form
-                if (b0 + mrow < a.g.degu) { my_order = gload_u32(&a.g.up_adj_order[rowi + b0 + mrow]); my_slot = gload_u32(&a.g.up_adj_slot[rowi + b0 + mrow]); }
+                if (b0 + mrow < a.g.degu) { my_order = a.g.up_adj_order[rowi + b0 + mrow]; my_slot = a.g.up_adj_slot[rowi + b0 + mrow]; }
                 const bool live = my_order != kEmpty;
                 used_ovf = false;
                 const bool fresh = live && visited_insert<BUCKET>(vs, nullptr, my_order, vis_ovf, used_ovf);
@@ -935,7 +921,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
                 }
             }
         }
-        if (!fail) cur_slot = gload_u32(&a.g.up_down[base + cur_slot]);      // changeLayer, src/hnsw.h:575-587
+        if (!fail) cur_slot = a.g.up_down[base + cur_slot];      // changeLayer, src/hnsw.h:575-587
     }
     st.n_visited_up = nvis;
     DIAG_STAMP(t_up_end);
@@ -968,7 +954,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
                 const uint2 c = C[0];
                 ckey = rfl(c.x); cid = rfl(c.y);
                 // the candidate's neighbour list is requested now and arrives while the heap is repaired
-                if (mrow < a.g.deg0) my = gload_u32(&a.g.adj0[(size_t)cid * a.g.deg0 + mrow]);
+                if (mrow < a.g.deg0) my = a.g.adj0[(size_t)cid * a.g.deg0 + mrow];
                 if (nC > 1) {
                     heap_pop_wave<COrder>(C, nC, lane);
                 }
@@ -1099,7 +1085,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
                 // the live entries of a list are a prefix: a batch with a gap was the last one
                 b0 += RM::kRowsPerBatch;
                 if (b0 >= a.g.deg0 || nlive < (uint32_t)RM::kRowsPerBatch) break;
-                my = b0 + mrow < a.g.deg0 ? gload_u32(&a.g.adj0[(size_t)cid * a.g.deg0 + b0 + mrow]) : kEmpty;
+                my = b0 + mrow < a.g.deg0 ? a.g.adj0[(size_t)cid * a.g.deg0 + b0 + mrow] : kEmpty;
             }
         }
     }
@@ -1220,11 +1206,12 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(SearchArgs a)
         if (a.out_count) a.out_count[qi] = nW;
         if (a.stats) a.stats[qi] = st;
 #ifndef HNSW_DIAG
-        // what this query needed of its scratch, for the sizing of later batches (the word is read rarely
-        // changed: most queries stay below the running maximum)
+        // What this query needed of its scratch, for the sizing of later batches.  Only a query that goes beyond what
+        // the launcher already knows (a.known_*) touches device memory for it — in the steady state none does — and even
+        // then the word is read first: most queries stay below the running maximum.
         const uint32_t vmax = st.n_visited0 > st.n_visited_up ? st.n_visited0 : st.n_visited_up;
-        if (vmax > __hip_atomic_load(&a.fail_count[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&a.fail_count[1], vmax);
-        if (c_need > __hip_atomic_load(&a.fail_count[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&a.fail_count[2], c_need);
+        if (vmax > a.known_visit && vmax > __hip_atomic_load(&a.fail_count[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&a.fail_count[1], vmax);
+        if (c_need > a.known_c && c_need > __hip_atomic_load(&a.fail_count[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&a.fail_count[2], c_need);
         // (the mean from one query in 32: atomics to one address are served one after the other, and ten thousand
         // of them take longer than a whole batch)
         if ((qi & 31u) == 0u) { atomicAdd(&a.fail_count[4], vmax >> 4); atomicAdd(&a.fail_count[5], 1u); }
@@ -1324,8 +1311,7 @@ void DeviceIndex::release()
     if (d_spill) (void)hipFree(d_spill);
     d_spill = nullptr;
     if (h_fail) (void)hipHostFree(h_fail);
-    if (ev_done) (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(ev_done));
-    ev_done = nullptr;
+
     d_fail = nullptr; h_fail = nullptr; fail_cap = 0;
     version = ~0ull;
 }
@@ -1402,7 +1388,6 @@ void DeviceIndex::upload(const HostIndex& h, int dev)
     // set-up for the search calls: the pinned word the overflow count is read into, and this GPU's address of the
     // static scratch array (so that a search call itself never has to allocate or look anything up)
     if (!h_fail) HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_fail), 64, hipHostMallocDefault));
-    if (!ev_done) HIP_CHECK(hipEventCreateWithFlags(reinterpret_cast<hipEvent_t*>(&ev_done), hipEventDisableTiming));
     (void)noalloc_scratch_for(dev, true);
     version = h.version_;
     learn_flags = 0; learn_ef = 0; learn_visit = 0; learn_c = 0; learn_mean = 0;
@@ -1612,7 +1597,7 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
     if (no_alloc) {
         // this GPU's copy of the static scratch array, through the address looked up at upload (never the array's name)
         list_a = noalloc_scratch_for(device, false);
-        if (!list_a || !h_fail || !ev_done) throw std::logic_error("search (no-allocation entry point): the index was not set up on this device");
+        if (!list_a || !h_fail) throw std::logic_error("search (no-allocation entry point): the index was not set up on this device");
         list_b = list_a + (kNoAllocMaxQueries + kFailHeader);
     } else {
         if (fail_cap < nq + kFailHeader) {
@@ -1643,10 +1628,12 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
     a.out_ids = d_ids; a.out_dist = d_dist; a.out_count = d_count; a.stats = d_stats;
     const bool scalar = (flags & HNSW_AMD_DIST_SCALAR) != 0;
 
-    int max_lds = 0, num_cus = 0;
-    HIP_CHECK(hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device));
-    HIP_CHECK(hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, device));
-    if (num_cus < 1) num_cus = 1;
+    if (dev_max_lds == 0) {
+        HIP_CHECK(hipDeviceGetAttribute(&dev_max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device));
+        HIP_CHECK(hipDeviceGetAttribute(&dev_num_cus, hipDeviceAttributeMultiprocessorCount, device));
+        if (dev_num_cus < 1) dev_num_cus = 1;
+    }
+    const int max_lds = dev_max_lds, num_cus = dev_num_cus;
 
     // ---- what the queries of this batch are expected to need ----
     // Sized from what earlier batches on this index were seen to need (the kernel reports the largest visited
@@ -1655,6 +1642,7 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
     // times the estimate, such as unit-norm vectors under the reference's int32 keys, do so at every ef).
     if (flags != learn_flags) { learn_flags = flags; learn_ef = 0; learn_visit = 0; learn_c = 0; learn_mean = 0; }
     uint32_t want_visit0 = visit_estimate(ef), want_c0 = heap_estimate(ef);
+    a.known_visit = 0; a.known_c = 0;
     // what the bulk of the queries needs (bucket form with spill tables: the few beyond it continue in device memory)
     uint32_t want_bulk0 = 0;
     if (learn_ef == ef) {
@@ -1662,6 +1650,9 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
         if (const char* e = getenv("HNSW_AMD_BULK_FRAC")) frac = (float)atof(e);      // tuning
         if (learn_mean > 0 && learn_mean < learn_visit) want_bulk0 = learn_mean + (uint32_t)(frac * (float)(learn_visit - learn_mean));
         want_visit0 = learn_visit + learn_visit / 20u + 16u;
+        // (queries report only what goes beyond what is known; one batch in 64 reports in full, so that the known
+        // values can also come down)
+        if ((++learn_age & 63u) != 0u) { a.known_visit = learn_visit; a.known_c = learn_c; }
         want_c0 = learn_c + learn_c / 32u + 4u;          // (learn_c is what the overflow test asked for, not the heap's size)
     } else if (learn_ef != 0) {
         const float rv = std::max(1.0f, 1.2f * (float)learn_visit / (float)visit_estimate(learn_ef));
@@ -1708,9 +1699,14 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
             const bool force16 = getenv("HNSW_AMD_VISITED16") != nullptr, forceb = getenv("HNSW_AMD_VISITEDB") != nullptr;
             if (!getenv("HNSW_AMD_VISITED32") && (force16 || forceb || lds > budget)) {
                 auto occupancy = [&](size_t bytes, bool bucket = false) {
+                    if (bytes > 65536) return (int)(kLdsPerCu / bytes);
+                    // (asked of the runtime once per kernel and size: the call costs microseconds, a batch a few hundred)
+                    const void* fn = reinterpret_cast<const void*>(bucket ? kern_b : kern_p);
+                    for (const OccupancyNote& o : occupancy_notes) if (o.kernel == fn && o.bytes == bytes) return o.blocks;
                     int occ = 0;
-                    if (bytes <= 65536) HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(bucket ? kern_b : kern_p), 64, bytes));
-                    else occ = (int)(kLdsPerCu / bytes);
+                    HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, 64, bytes));
+                    if (occupancy_notes.size() >= 64) occupancy_notes.clear();
+                    occupancy_notes.push_back({fn, bytes, occ});
                     return occ;
                 };
                 auto bucket_args = [&](uint32_t want, BucketShape& sh, SearchArgs& out) -> size_t {
@@ -1771,6 +1767,7 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
         const SearchKernel kern = a.vis_chunks ? kern_b : kern_p;
         a.fail_count = cur; a.fail_list = cur + kFailHeader;
         HIP_CHECK(hipMemsetAsync(cur, 0, 4 * kFailHeader, stream));
+        h_fail[kFailHeader - 1] = 0xFFFFFFFFu;               // (the report replaces it with the header's zero)
         if (lds > 32768)
             HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         if (const char* pad = getenv("HNSW_AMD_LDS_PAD")) lds += (size_t)atoi(pad);      // occupancy experiments
@@ -1801,12 +1798,28 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
         }
         if (!sync_and_retry) return 0;
         if (copy_back) HIP_CHECK(hipMemcpyAsync(copy_back->dst, copy_back->src, copy_back->bytes, hipMemcpyDeviceToHost, stream));
+        // The launch's report travels to a pinned host buffer whose last word the host has set to all ones and the device
+        // copy holds as zero (cleared with the rest of the header before the launch, never written by the kernel), and
+        // the host waits by watching that word: no stream synchronisation (the caller's stream is often the legacy default stream, whose
+        // synchronisation also covers whatever other threads of the process keep adding to it or to streams it
+        // synchronises with), no event, nothing to wake up — measured 20 us per call less than an event wait, which is
+        // 4 % of a 10 000-query batch at ef=20.  The stream is queried now and then so that an error ends the wait.
         HIP_CHECK(hipMemcpyAsync(h_fail, cur, 4 * kFailHeader, hipMemcpyDeviceToHost, stream));
-        // Wait for exactly this point of the stream (an event), not for the stream: the caller's stream is often the
-        // legacy default stream, whose synchronisation also covers whatever other threads of the process (a
-        // collective library's workers) keep adding to it or to streams it synchronises with.
-        HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_done), stream));
-        HIP_CHECK(hipEventSynchronize(reinterpret_cast<hipEvent_t>(ev_done)));
+        volatile uint32_t* report = h_fail;
+        for (uint32_t spins = 0; report[kFailHeader - 1] != 0u; spins++) {
+            __builtin_ia32_pause();
+            if ((spins & 0xFFFu) == 0xFFFu) {
+                const hipError_t q = hipStreamQuery(stream);
+                if (q == hipSuccess) {
+                    // everything queued has run: the report is in memory (or never will be)
+                    if (report[kFailHeader - 1] != 0u) HIP_CHECK(hipStreamSynchronize(stream));
+                    if (report[kFailHeader - 1] != 0u) throw std::runtime_error("HIP: the launch's report did not arrive");
+                    break;
+                }
+                if (q != hipErrorNotReady) HIP_CHECK(q);
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
 #ifdef HNSW_CHECKS
         {
             uint32_t bad = 0;
@@ -1828,12 +1841,17 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
     }
     // remember what this batch needed (the maxima are those of the queries that finished, i.e. of all of them)
     const uint32_t seen_mean = seen_done ? (uint32_t)(seen_sum16 * 16u / seen_done) : 0u;
-    if (seen_visit == 0) {
+    if (seen_visit == 0 && learn_ef != ef) {
         // (a diagnostic build of the kernel reports nothing)
     } else if (learn_ef == ef) {
-        // grows at once, shrinks slowly (one far-reaching query should not cost residency for ever)
-        learn_visit = std::max(seen_visit, (uint32_t)(((uint64_t)learn_visit * 15u + seen_visit) / 16u));
-        learn_c = std::max(seen_c, (uint32_t)(((uint64_t)learn_c * 15u + seen_c) / 16u));
+        // Grows at once, shrinks slowly (one far-reaching query should not cost residency for ever).  A launch that
+        // was told the known maxima reports only what went beyond them.
+        if (a.known_visit) {
+            learn_visit = std::max(learn_visit, seen_visit); learn_c = std::max(learn_c, seen_c);
+        } else if (seen_visit) {
+            learn_visit = std::max(seen_visit, (uint32_t)(((uint64_t)learn_visit * 15u + seen_visit) / 16u));
+            learn_c = std::max(seen_c, (uint32_t)(((uint64_t)learn_c * 15u + seen_c) / 16u));
+        }
         if (nq >= 64) learn_mean = (uint32_t)(((uint64_t)learn_mean * 3u + seen_mean) / 4u);
     } else if (nq >= 64 || learn_ef == 0) {
         learn_ef = ef; learn_visit = seen_visit; learn_c = seen_c; learn_mean = nq >= 64 ? seen_mean : 0u;

@@ -24,14 +24,16 @@ class HNSW:
     def __init__(self, M: int, Mmax: int, efConstruction: int, device: int = 0):
         self._h = C.c_void_p()
         capi.check(capi.lib().hnsw_amd_create(M, Mmax, efConstruction, C.byref(self._h)))
+        self._destroy = capi.lib().hnsw_amd_destroy      # (kept here: module globals may be gone when __del__ runs at exit)
         self.device = device
         self.W_: list[Neighbors] = []
         self.flags = capi.DIST_SSE | capi.KEYS_INT32
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
-            capi.lib().hnsw_amd_destroy(h)
+        destroy = getattr(self, "_destroy", None)
+        if h and destroy is not None:
+            destroy(h)
 
     # -- reference API ----------------------------------------------------------------
     def init(self, vector_size: int, max_node_count: int) -> None:

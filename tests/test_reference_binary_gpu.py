@@ -21,6 +21,7 @@ pytestmark = pytest.mark.gpu
     ("sift", "sse", capi.DIST_SSE | capi.ROWS_U8, 100_000, (50,)),
     ("fmnist", "sse", capi.DIST_SSE, 20_000, (64,)),
     ("deep", "sse", capi.DIST_SSE | capi.W_STD_HEAP, 40_000, (20,)),
+    ("gist", "sse", capi.DIST_SSE, 15_000, (40, 100)),
     ("glove", "scalar", capi.DIST_SCALAR | capi.W_STD_HEAP, 40_000, (10,)),
 ])
 def test_kernel_matches_the_reference_binary(tmp_path, kind, build, flags, n, efs):

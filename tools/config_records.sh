@@ -21,6 +21,9 @@ b)
 d)
   run deep96_12.5M_single_shard_float_build_keys --kind deep --base-size 12500000 --build-keys float --cpu-baseline none
   ;;
+e)
+  run sift128_1m_reference_ef_sweep --sweep 20,30,40,50,60,70,80,90,100,120,140,160,180,200 --cpu-baseline none
+  ;;
 c)
   run glove100_1.18M_sse_float_sweep --kind glove --base-size 1183514 --keys float --sweep 20,40,60,100 --cpu-baseline none &&
   run glove100_1.18M_sse_float_q8_sweep --kind glove --base-size 1183514 --keys float --rows q8 --sweep 20,40,60,100 --cpu-baseline none &&

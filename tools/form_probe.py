@@ -24,6 +24,8 @@ ap.add_argument("--build-keys", default="float")
 ap.add_argument("--rb-min", default="")
 ap.add_argument("--forms", default="auto,32,16,B")
 ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--dist", default="sse", choices=["sse", "scalar"])
+ap.add_argument("--keys", default="int32", choices=["int32", "float"])
 a = ap.parse_args()
 d = datagen.KINDS[a.kind]
 base = datagen.make(a.kind, a.n, seed=1)
@@ -43,7 +45,7 @@ ids = torch.empty((nq, 10), dtype=torch.int32, device="cuda")
 ds = torch.empty((nq, 10), dtype=torch.float32, device="cuda")
 cnt = torch.empty((nq,), dtype=torch.int32, device="cuda")
 st_t = torch.empty((nq, 8), dtype=torch.int32, device="cuda")
-flags = capi.DIST_SSE | capi.KEYS_INT32
+flags = (capi.DIST_SCALAR if a.dist == "scalar" else capi.DIST_SSE) | (capi.KEYS_FLOAT if a.keys == "float" else capi.KEYS_INT32)
 stream = torch.cuda.current_stream().cuda_stream
 if a.rb_min:
     os.environ["HNSW_AMD_VIS_RB_MIN"] = a.rb_min
@@ -68,7 +70,7 @@ for ef in [int(x) for x in a.ef.split(",")]:
             retried = h.search_batch_device(q_t.data_ptr(), nq, ef, 10, ids.data_ptr(), ds.data_ptr(), cnt.data_ptr(), st_t.data_ptr(), stream, flags)
             torch.cuda.synchronize()
             st = st_t.cpu().numpy().view(np.uint32).reshape(nq, 8).copy().view(capi.STATS_DTYPE).reshape(nq)
-            byts = int(harness.algorithmic_bytes(st, d, d & ~15, 10, 4).sum())
+            byts = int(harness.algorithmic_bytes(st, d, d if a.dist == "scalar" else d & ~15, 10, 4).sum())
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(a.reps):
