@@ -4,7 +4,7 @@
 //   d2(q, x) = |q|^2 + |x|^2 - 2 q.x
 //
 // The q.x part is a GEMM computed with the f32-input MFMA (v_mfma_f32_32x32x2_f32: f32 in,
-// f32 accumulate, bit-for-bit a k-ordered fmaf chain), so for the integer-valued sets every
+// f32 accumulate, bit-for-bit an fmaf chain over k in a fixed order), so for the integer-valued sets every
 // distance is exact.  Base rows are processed in chunks.  The first chunk (a few thousand rows)
 // goes the plain way: a tile kernel writes its distance matrix, a selection kernel (one
 // wavefront per query) folds it into the running top-k.  From then on every query has a
@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 
@@ -43,7 +44,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kBM = 128;        // queries per block tile
 constexpr int kBN = 128;        // base rows per block tile
 constexpr int kBK = 32;         // k per staging step
-constexpr int kLd = kBM + 4;    // LDS row length (floats): tiles are stored k-major, [k][row]
+constexpr int kLd = kBK + 4;    // LDS row length (floats): tiles are stored as they lie in memory, [row][k]; 36 makes the 16-byte reads
+                                // of a lane group (16 rows, 4 banks each) cover the 64 banks exactly once
 
 __global__ void row_norms_kernel(const float* x, uint32_t n, uint32_t d, float* out)
 {
@@ -55,6 +57,8 @@ __global__ void row_norms_kernel(const float* x, uint32_t n, uint32_t d, float* 
     for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
     if (lane == 0) out[row] = s;
 }
+
+__device__ __forceinline__ float el(const float4& v, int e) { return e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w)); }
 
 // What the tile kernel does with a tile's distances when it filters them itself (EMIT).
 struct EmitArgs {
@@ -70,142 +74,195 @@ struct EmitArgs {
 // EMIT = false: written to D[q][j].  EMIT = true: appended to query q's candidate list when it does not exceed the
 // query's threshold.
 // 256 threads = 4 waves in 2 x 2; each wave owns a 64 x 64 part = 2 x 2 MFMA tiles of 32 x 32.
-template <bool EMIT>
+// VEC: rows are a multiple of 4 floats long (16-byte loads).
+// Grid: x = tile of 128 queries, y = worker; a worker takes the column tiles y, y + gridDim.y, ... of the chunk one after
+// the other (the blocks that share a column tile sit next to each other in launch order, so a tile of base rows is
+// fetched from memory about once and then served by the L2s), and asks for its next tile's first operands before it
+// turns to the distances of the current one.
+template <bool EMIT, bool VEC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void dist_tile_kernel(const float* __restrict__ Q, const float* __restrict__ X,
                                                         const float* __restrict__ qn, const float* __restrict__ xn,
-                                                        uint32_t nq, uint32_t n, uint32_t d, uint32_t x0, uint32_t cw,
+                                                        uint32_t nq, uint32_t n, uint32_t d, uint32_t x0, uint32_t cw, uint32_t ntx,
                                                         float* __restrict__ D, EmitArgs em)
 {
-    __shared__ __align__(16) float As[kBK * kLd];
-    __shared__ __align__(16) float Bs[kBK * kLd];
+    __shared__ __align__(16) float As[kBM * kLd];
+    __shared__ __align__(16) float Bs[kBN * kLd];
+    __shared__ __align__(16) float qn_s[kBM];
+    __shared__ __align__(16) float thr_s[kBM];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    const uint32_t q0 = blockIdx.y * kBM, j0 = blockIdx.x * kBN;       // tile origin (query, column of the chunk)
+    const uint32_t q0 = blockIdx.x * kBM;                  // first query of the tile
+    uint32_t jt = blockIdx.y;                              // column tile in hand
+    if (jt >= ntx) return;
 
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-        for (int b = 0; b < 2; b++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[a][b][r] = 0.0f;
-
-    // staging role: row r of the tile, 16 consecutive k starting at 16*kh
-    const int sr = tid & 127, kh = tid >> 7;
-    const uint32_t qrow = q0 + sr, xcol = j0 + sr;
-    const bool qok = qrow < nq, xok = xcol < cw && x0 + xcol < n;
-    const float* qp = Q + (size_t)(qok ? qrow : 0) * d;
-    const float* xp = X + (size_t)(xok ? x0 + xcol : 0) * d;
-    // compute role
-    const int fi = lane & 31, fk = lane >> 5;
-
-    // The 16 + 16 values of the next k step are fetched into registers while the matrix cores work on
-    // the current one (16-byte loads when the rows allow it).
-    float ra[16], rb[16];
-    const bool vec = (d & 3u) == 0;
-    auto fetch = [&](uint32_t k0) {
-        const uint32_t kb = k0 + 16 * kh;
-        if (vec) {
-            // always load (rows outside the tile read row 0, groups past the end of a row its last group) and zero
-            // afterwards: selects instead of a branch around every load
-#pragma unroll
-            for (int j = 0; j < 16; j += 4) {
-                const bool inside = kb + j < d;                 // d % 4 == 0: a group of 4 is inside the row or outside it
-                const uint32_t kc = inside ? kb + j : d - 4u;
-                float4 va = *reinterpret_cast<const float4*>(qp + kc);
-                float4 vb = *reinterpret_cast<const float4*>(xp + kc);
-                if (!(inside && qok)) va = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (!(inside && xok)) vb = make_float4(0.f, 0.f, 0.f, 0.f);
-                ra[j] = va.x; ra[j + 1] = va.y; ra[j + 2] = va.z; ra[j + 3] = va.w;
-                rb[j] = vb.x; rb[j + 1] = vb.y; rb[j + 2] = vb.z; rb[j + 3] = vb.w;
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 16; j++) {
-                const uint32_t k = kb + j;
-                ra[j] = (qok && k < d) ? qp[k] : 0.0f;
-                rb[j] = (xok && k < d) ? xp[k] : 0.0f;
-            }
-        }
-    };
-    fetch(0);
-    for (uint32_t k0 = 0; k0 < d; k0 += kBK) {
-#pragma unroll
-        for (int j = 0; j < 16; j++) {
-            As[(16 * kh + j) * kLd + sr] = ra[j];
-            Bs[(16 * kh + j) * kLd + sr] = rb[j];
-        }
-        __syncthreads();
-        if (k0 + kBK < d) fetch(k0 + kBK);
-#pragma unroll
-        for (int kk = 0; kk < kBK; kk += 2) {
-            float a[2], b[2];
-#pragma unroll
-            for (int t = 0; t < 2; t++) {
-                a[t] = As[(kk + fk) * kLd + wr * 64 + t * 32 + fi];
-                b[t] = Bs[(kk + fk) * kLd + wc * 64 + t * 32 + fi];
-            }
-#pragma unroll
-            for (int ta = 0; ta < 2; ta++)
-#pragma unroll
-                for (int tb = 0; tb < 2; tb++) acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
-        }
-        __syncthreads();
-    }
-    // the tile's query norms and (EMIT) thresholds, staged once in the LDS the operands no longer need
-    float* qn_s = As;
-    float* thr_s = As + kBM;
+    // the tile's query norms and (EMIT) thresholds (the first barrier of the k loop publishes them)
     if (tid < kBM) {
         const uint32_t row = q0 + tid;
         qn_s[tid] = row < nq ? qn[row] : 0.0f;
         if (EMIT) thr_s[tid] = row < nq ? em.best_d[(size_t)row * em.kp + em.kp - 1] : -__builtin_inff();
     }
-    __syncthreads();
-    // C layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5): a lane's 16
-    // registers are 4 groups of 4 consecutive rows, so the rows' norms and thresholds are 4 + 4 16-byte LDS reads
+
+    // Staging role: the group of 4 consecutive k numbered sc, of rows sr0, sr0 + 32, sr0 + 64, sr0 + 96 of both tiles:
+    // eight lanes fetch the 128 contiguous bytes a row contributes to a k step, and store them to LDS as they are.
+    // Rows outside the tile read the tile's first row instead: what is computed from them is never looked at (the
+    // epilogue skips columns and rows outside), and only k beyond the end of a row has to contribute zero — to one operand.
+    const int sc = tid & 7, sr0 = tid >> 3;
+    const float* qt = Q + (size_t)q0 * d;
+    const float* xt = nullptr;
+    uint32_t xj0 = 0;                         // first column of the tile the staging role points at
+    auto aim = [&](uint32_t tile) {           // point the staging role at a column tile
+        xj0 = tile * kBN;
+        xt = X + ((size_t)x0 + xj0) * d;
+    };
+    // (row offsets are recomputed at every fetch: eight registers less to carry through the matrix instructions)
+    auto qoff = [&](int i) { const uint32_t r = (uint32_t)(sr0 + 32 * i); return (q0 + r < nq ? r : 0u) * d; };
+    auto xoff = [&](int i) { const uint32_t r = (uint32_t)(sr0 + 32 * i); return ((xj0 + r < cw && x0 + xj0 + r < n) ? r : 0u) * d; };
+    // compute role
+    const int fi = lane & 31, fk = lane >> 5;
+
+    // The 4 + 4 groups of the next k step are fetched into registers while the matrix cores work on the current one
+    // (16-byte loads when the rows allow it).
+    // Nothing touches the fetched registers before the store to LDS one step later (the zero for k beyond the end of a row
+    // is selected there): a use any earlier would put the wait for the loads in front of the matrix instructions.
+    float ra[16], rb[16];
+    bool inside = true;                 // of the values in flight: is their k inside the row
+    auto fetch = [&](uint32_t k0) {
+        const uint32_t kb = k0 + 4u * (uint32_t)sc;
+        if constexpr (VEC) {
+            // always load (groups past the end of a row read its last group)
+            inside = kb < d;                                    // d % 4 == 0: a group of 4 is inside the row or outside it
+            const uint32_t kc = inside ? kb : d - 4u;
 #pragma unroll
-    for (int ta = 0; ta < 2; ta++) {
-        float4 qv[4], tv[4];
+            for (int i = 0; i < 4; i++) {
+                const float4 va = *reinterpret_cast<const float4*>(qt + qoff(i) + kc);
+                const float4 vb = *reinterpret_cast<const float4*>(xt + xoff(i) + kc);
+                ra[4 * i] = va.x; ra[4 * i + 1] = va.y; ra[4 * i + 2] = va.z; ra[4 * i + 3] = va.w;
+                rb[4 * i] = vb.x; rb[4 * i + 1] = vb.y; rb[4 * i + 2] = vb.z; rb[4 * i + 3] = vb.w;
+            }
+        } else {
 #pragma unroll
-        for (int g = 0; g < 4; g++) {
-            const int base = wr * 64 + ta * 32 + 8 * g + 4 * (lane >> 5);
-            qv[g] = *reinterpret_cast<const float4*>(qn_s + base);
-            if (EMIT) tv[g] = *reinterpret_cast<const float4*>(thr_s + base);
+            for (int i = 0; i < 4; i++) {
+                const float* qr = qt + qoff(i);
+                const float* xr = xt + xoff(i);
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    ra[4 * i + e] = kb + e < d ? qr[kb + e] : 0.0f;
+                    rb[4 * i + e] = kb + e < d ? xr[kb + e] : 0.0f;
+                }
+            }
         }
-        auto pick = [](const float4& v, int e) { return e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w)); };
+    };
+    aim(jt);
+    fetch(0);
+    for (; jt < ntx; jt += gridDim.y) {
+        const uint32_t j0 = jt * kBN;
+        // the norms of this lane's two columns, asked for now and used after the k loop
+        float xv[2];
+        bool col_ok[2];
 #pragma unroll
         for (int tb = 0; tb < 2; tb++) {
             const uint32_t col = j0 + wc * 64 + tb * 32 + (lane & 31);
-            const bool col_ok = col < cw && x0 + col < n;
-            const float xv = col_ok ? xn[x0 + col] : 0.0f;
-            float dist[16];
-            uint32_t pass = 0;
+            col_ok[tb] = col < cw && x0 + col < n;
+            xv[tb] = xn[col_ok[tb] ? x0 + col : x0 + j0];
+        }
+        f32x16 acc[2][2];
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                dist[r] = (pick(qv[r >> 2], r & 3) + xv) - 2.0f * acc[ta][tb][r];
-                if (EMIT) pass |= (dist[r] <= pick(tv[r >> 2], r & 3) ? 1u : 0u) << r;      // (rows past nq have threshold -inf)
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[a][b][r] = 0.0f;
+
+        for (uint32_t k0 = 0; k0 < d; k0 += kBK) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                *reinterpret_cast<float4*>(&As[(sr0 + 32 * i) * kLd + 4 * sc]) =
+                    make_float4(inside ? ra[4 * i] : 0.f, inside ? ra[4 * i + 1] : 0.f, inside ? ra[4 * i + 2] : 0.f, inside ? ra[4 * i + 3] : 0.f);
+                *reinterpret_cast<float4*>(&Bs[(sr0 + 32 * i) * kLd + 4 * sc]) = make_float4(rb[4 * i], rb[4 * i + 1], rb[4 * i + 2], rb[4 * i + 3]);
             }
-            if constexpr (EMIT) {
-                if (!col_ok) pass = 0;
-                if (__ballot(pass != 0u) == 0ull) continue;          // nothing of this 32 x 32 part survives: the common case late in the scan
+            __syncthreads();
+            if (k0 + kBK < d) fetch(k0 + kBK);
+            else if (jt + gridDim.y < ntx) { aim(jt + gridDim.y); fetch(0); }       // the next tile's first step
+            // One 16-byte LDS read hands a lane the operands of four matrix instructions: the lane of row fi and half fk takes
+            // k = 8 j + 4 fk + e for e = 0..3, so instruction (j, e) multiplies k = 8 j + e (lower half of the wave) and
+            // k = 8 j + 4 + e (upper half) — every k of the step exactly once, in an order that is the same for every output.
+            // (the reads of group j + 1 are issued before the matrix instructions of group j)
+            float4 a[2], b[2];
+            auto read_group = [&](int j, float4 (&av)[2], float4 (&bv)[2]) {
 #pragma unroll
-                for (int r = 0; r < 16; r++)
-                    if ((pass >> r) & 1u) {
-                        const uint32_t row = q0 + wr * 64 + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                        const uint32_t at = atomicAdd(&em.cnt[row], 1u);
-                        if (at < em.cap) em.cand[(size_t)row * em.cap + at] = make_uint2(__float_as_uint(dist[r]), em.id_offset + x0 + col);
+                for (int t = 0; t < 2; t++) {
+                    av[t] = *reinterpret_cast<const float4*>(&As[(wr * 64 + t * 32 + fi) * kLd + 8 * j + 4 * fk]);
+                    bv[t] = *reinterpret_cast<const float4*>(&Bs[(wc * 64 + t * 32 + fi) * kLd + 8 * j + 4 * fk]);
+                }
+            };
+            read_group(0, a, b);
+#pragma unroll
+            for (int j = 0; j < kBK / 8; j++) {
+                float4 an[2], bn[2];
+                if (j + 1 < kBK / 8) read_group(j + 1, an, bn);
+                __builtin_amdgcn_sched_barrier(0);          // (the scheduler would otherwise sink the reads to where their registers free up)
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+#pragma unroll
+                    for (int ta = 0; ta < 2; ta++)
+#pragma unroll
+                        for (int tb = 0; tb < 2; tb++)
+                            acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(el(a[ta], e), el(b[tb], e), acc[ta][tb], 0, 0, 0);
+                if (j + 1 < kBK / 8) {
+#pragma unroll
+                    for (int t = 0; t < 2; t++) { a[t] = an[t]; b[t] = bn[t]; }
+                }
+            }
+            __syncthreads();
+        }
+        // C layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5): a lane's 16
+        // registers are 4 groups of 4 consecutive rows, so a group's norms and thresholds are one 16-byte LDS read each
+        // (read where they are used: the operands of the next tile are in flight and registers are short)
+        uint32_t row_base = q0 + (uint32_t)(wr * 64 + 4 * (lane >> 5));
+        asm volatile("" : "+v"(row_base));        // (keeps the 64 row addresses of the rare emission from being carried through the k loop)
+#pragma unroll
+        for (int ta = 0; ta < 2; ta++) {
+#pragma unroll
+            for (int tb = 0; tb < 2; tb++) {
+                const uint32_t col = j0 + wc * 64 + tb * 32 + (lane & 31);
+                float dist[16];
+                uint32_t pass = 0;
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int base = wr * 64 + ta * 32 + 8 * g + 4 * (lane >> 5);
+                    const float4 qv = *reinterpret_cast<const float4*>(qn_s + base);
+                    float4 tv = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (EMIT) tv = *reinterpret_cast<const float4*>(thr_s + base);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int r = 4 * g + e;
+                        dist[r] = (el(qv, e) + xv[tb]) - 2.0f * acc[ta][tb][r];
+                        if (EMIT) pass |= (dist[r] <= el(tv, e) ? 1u : 0u) << r;      // (rows past nq have threshold -inf)
                     }
-            } else {
-                if (!col_ok) continue;
+                }
+                if constexpr (EMIT) {
+                    if (!col_ok[tb]) pass = 0;
+                    if (__ballot(pass != 0u) == 0ull) continue;          // nothing of this 32 x 32 part survives: the common case late in the scan
 #pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const uint32_t row = q0 + wr * 64 + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    if (row < nq) D[(size_t)row * cw + col] = dist[r];
+                    for (int r = 0; r < 16; r++)
+                        if ((pass >> r) & 1u) {
+                            const uint32_t row = row_base + (uint32_t)(ta * 32 + (r & 3) + 8 * (r >> 2));
+                            const uint32_t at = atomicAdd(&em.cnt[row], 1u);
+                            if (at < em.cap) em.cand[(size_t)row * em.cap + at] = make_uint2(__float_as_uint(dist[r]), em.id_offset + x0 + col);
+                        }
+                } else {
+                    if (!col_ok[tb]) continue;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const uint32_t row = row_base + (uint32_t)(ta * 32 + (r & 3) + 8 * (r >> 2));
+                        if (row < nq) D[(size_t)row * cw + col] = dist[r];
+                    }
                 }
             }
         }
     }
 }
+
 
 // PAIRS = false: the candidates are row q of the chunk's distance matrix D (n_valid columns, ids id_offset + x0 + j);
 //   with `only_flagged`, queries whose flag is clear are skipped (they took the other path for this chunk).
@@ -325,6 +382,7 @@ float bruteforce_knn(const float* d_base, uint32_t n, const float* d_queries, ui
     if (n == 0 || nq == 0 || d == 0 || k == 0 || k > 128) throw std::invalid_argument("bruteforce_knn: need n, nq, d >= 1 and 1 <= k <= 128");
     hipStream_t stream = (hipStream_t)stream_v;
     const uint32_t kp = k + 8;                        // kept entries: a margin beyond k for the final re-scoring
+    const bool vec = (d & 3u) == 0 && ((uintptr_t)d_base & 15u) == 0 && ((uintptr_t)d_queries & 15u) == 0;
     constexpr uint32_t kCap = 1024;                   // candidate list per query and chunk
     // plain path: distance matrix of at most about 1 GiB at a time
     const uint32_t cw = (uint32_t)std::min<uint64_t>(n, std::max<uint64_t>(kBN, ((1ull << 28) / nq) / kBN * kBN));
@@ -365,13 +423,22 @@ float bruteforce_knn(const float* d_base, uint32_t n, const float* d_queries, ui
             BF_CHECK(hipEventElapsedTime(&ms, e0, e1));
             mfma_ms += ms;
         };
+        // column-tile workers of a launch: up to 8 tiles each, as long as that leaves the chip several rounds of blocks
+        const uint32_t nty = (nq + kBM - 1) / kBM;
+        auto workers_for = [&](uint32_t ntx) {
+            uint32_t per = 8;
+            while (per > 1 && (uint64_t)((ntx + per - 1) / per) * nty < 4096u) per >>= 1;
+            if (const char* e = getenv("HNSW_AMD_BF_TILES_PER_WORKER")) per = (uint32_t)std::max(1, atoi(e));     // tests: the multi-tile path on small inputs
+            return (ntx + per - 1) / per;
+        };
         // rows [lo, hi) the plain way (for every query, or only for those whose flag is set)
         auto plain = [&](uint32_t lo, uint32_t hi, int only_flagged) {
             for (uint32_t x0 = lo; x0 < hi; x0 += cw) {
                 const uint32_t valid = std::min(cw, hi - x0);
                 timed([&] {
-                    hipLaunchKernelGGL(dist_tile_kernel<false>, dim3((valid + kBN - 1) / kBN, (nq + kBM - 1) / kBM), dim3(256), 0, stream,
-                                       d_queries, d_base, qn, xn, nq, n, d, x0, cw, D, EmitArgs{});
+                    const uint32_t ntx = (valid + kBN - 1) / kBN;
+                    hipLaunchKernelGGL((vec ? dist_tile_kernel<false, true> : dist_tile_kernel<false, false>), dim3((nq + kBM - 1) / kBM, workers_for(ntx)), dim3(256), 0, stream,
+                                       d_queries, d_base, qn, xn, nq, n, d, x0, cw, ntx, D, EmitArgs{});
                 });
                 hipLaunchKernelGGL(select_topk_kernel<false>, dim3(nq), dim3(64), pool_bytes, stream, D, cw, x0, id_offset, valid, kp, best_d,
                                    best_i, (const uint2*)nullptr, (const uint32_t*)nullptr, 0u, flags, any_flag, only_flagged);
@@ -390,8 +457,9 @@ float bruteforce_knn(const float* d_base, uint32_t n, const float* d_queries, ui
             BF_CHECK(hipMemsetAsync(any_flag, 0, 4, stream));
             const EmitArgs em{best_d, kp, cand, cnt, kCap, id_offset};
             timed([&] {
-                hipLaunchKernelGGL(dist_tile_kernel<true>, dim3((width + kBN - 1) / kBN, (nq + kBM - 1) / kBM), dim3(256), 0, stream,
-                                   d_queries, d_base, qn, xn, nq, n, d, seen, width, (float*)nullptr, em);
+                const uint32_t ntx = (width + kBN - 1) / kBN;
+                hipLaunchKernelGGL((vec ? dist_tile_kernel<true, true> : dist_tile_kernel<true, false>), dim3((nq + kBM - 1) / kBM, workers_for(ntx)), dim3(256), 0, stream,
+                                   d_queries, d_base, qn, xn, nq, n, d, seen, width, ntx, (float*)nullptr, em);
             });
             hipLaunchKernelGGL(select_topk_kernel<true>, dim3(nq), dim3(64), pool_bytes, stream, (const float*)nullptr, 0u, 0u, id_offset, 0u, kp,
                                best_d, best_i, (const uint2*)cand, (const uint32_t*)cnt, kCap, flags, any_flag, 0);

@@ -9,9 +9,13 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("kind,n,nq,d,k", [("sift", 5000, 70, 128, 10), ("sift", 40000, 300, 128, 100), ("glove", 7000, 33, 100, 11),
-                                            ("fmnist", 3000, 20, 784, 10), ("sift", 130, 5, 19, 128)])
-def test_bruteforce_matches_cpu_scan(kind, n, nq, d, k):
+                                            ("fmnist", 3000, 20, 784, 10), ("sift", 130, 5, 19, 128),
+                                            ("deep", 70001, 200, 96, 10), ("glove", 50000, 130, 100, 10), ("sift", 20000, 129, 30, 5)])
+@pytest.mark.parametrize("tiles_per_worker", [None, "3"])
+def test_bruteforce_matches_cpu_scan(kind, n, nq, d, k, tiles_per_worker, monkeypatch):
     import torch
+    if tiles_per_worker:
+        monkeypatch.setenv("HNSW_AMD_BF_TILES_PER_WORKER", tiles_per_worker)      # (a block walks several column tiles)
     base = datagen.make(kind, n, seed=9, d=d)
     q = datagen.make(kind, nq, seed=9, stream=1, d=d)
     dist, ids, info = harness.exact_topk_mfma(torch.from_numpy(base).cuda(), torch.from_numpy(q).cuda(), k, id_offset=1000)
