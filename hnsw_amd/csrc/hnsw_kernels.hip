@@ -807,9 +807,11 @@ __device__ __forceinline__ uint32_t w_set_replace_max(uint32_t (&wd)[WR], uint32
 //       has to offer; the deep form (6) is for wide rows in a batch too small to fill the chip, where a CU holds
 //       only a few queries, registers are plentiful and nothing but a longer queue of loads hides the memory latency.
 // IP: inner-product metric (distance 1 - q.x) instead of squared L2; float rows, SSE order only.
-// (Except for the deep-prefetch form the kernels are held to 128 registers: four wavefronts per SIMD = 16 queries per CU.)
+// (Except for the deep-prefetch form the kernels are held to 128 registers: four wavefronts per SIMD = 16 queries per CU.
+// The one-lane-per-row kernel for ef > 128 gets 168: it would spill 24 registers at 128, and at those ef the LDS a query
+// needs leaves a CU fewer than 12 queries anyway.)
 template <bool SCALAR, int WR, int ROWS, bool BUCKET, int NBUF, bool IP>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBUF == 2 ? 4 : 1))) void hnsw_search_kernel(SearchArgs a)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBUF == 2 ? (SCALAR && WR == 4 ? 3 : 4) : 1))) void hnsw_search_kernel(SearchArgs a)
 {
     typedef RowMap<SCALAR> RM;
     typedef BatchLanes<SCALAR> BL;
