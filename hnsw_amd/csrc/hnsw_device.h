@@ -80,6 +80,9 @@ public:
     int learn_ef = 0;
     uint32_t learn_visit = 0, learn_c = 0;
     uint32_t learn_mean = 0;          // mean visited count of those batches
+    struct LearnNote { uint32_t flags; int ef; uint32_t visit, c, mean, age; };
+    std::vector<LearnNote> learn_notes;      // what batches with other flags / ef left (at most 16 kinds)
+    uint32_t learn_notes_next = 0;
     // last shapes computed for the bucket form of the visited set (the search over shapes is not free): sized for
     // the farthest-reaching query, and for the bulk of the queries
     BucketShape shape_full, shape_bulk;

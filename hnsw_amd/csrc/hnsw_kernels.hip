@@ -1392,7 +1392,7 @@ void DeviceIndex::upload(const HostIndex& h, int dev)
     if (!h_fail) HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_fail), 64, hipHostMallocDefault));
     (void)noalloc_scratch_for(dev, true);
     version = h.version_;
-    learn_flags = 0; learn_ef = 0; learn_visit = 0; learn_c = 0; learn_mean = 0;
+    learn_flags = 0; learn_ef = 0; learn_visit = 0; learn_c = 0; learn_mean = 0; learn_notes.clear();
     shape_full = BucketShape{}; shape_bulk = BucketShape{};
 }
 
@@ -1642,7 +1642,27 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
     // count and candidate heap of every launch): the same ef and flags with a twentieth of headroom, another ef by
     // the ratio of observation to estimate at the ef it was made at (data on which searches visit several
     // times the estimate, such as unit-norm vectors under the reference's int32 keys, do so at every ef).
-    if (flags != learn_flags) { learn_flags = flags; learn_ef = 0; learn_visit = 0; learn_c = 0; learn_mean = 0; }
+    if (flags != learn_flags || (learn_ef != 0 && learn_ef != ef)) {
+        // another kind of search than the last one: put what was learnt aside and take up what an earlier batch of this
+        // kind left (a caller that alternates between a few ef values keeps all of them sized)
+        if (learn_ef != 0) {
+            LearnNote note = {learn_flags, learn_ef, learn_visit, learn_c, learn_mean, learn_age};
+            bool put = false;
+            for (LearnNote& o : learn_notes) if (o.flags == note.flags && o.ef == note.ef) { o = note; put = true; }
+            if (!put) {
+                if (learn_notes.size() < 16) learn_notes.push_back(note);
+                else learn_notes[learn_notes_next++ % 16u] = note;
+            }
+        }
+        bool found = false;
+        for (const LearnNote& o : learn_notes)
+            if (o.flags == flags && o.ef == ef) {
+                learn_flags = o.flags; learn_ef = o.ef; learn_visit = o.visit; learn_c = o.c; learn_mean = o.mean; learn_age = o.age;
+                found = true;
+            }
+        // (nothing on this kind yet: with the same flags the last kind's figures, scaled, are the first guess)
+        if (!found && flags != learn_flags) { learn_flags = flags; learn_ef = 0; learn_visit = 0; learn_c = 0; learn_mean = 0; }
+    }
     uint32_t want_visit0 = visit_estimate(ef), want_c0 = heap_estimate(ef);
     a.known_visit = 0; a.known_c = 0;
     // what the bulk of the queries needs (bucket form with spill tables: the few beyond it continue in device memory)

@@ -211,6 +211,31 @@ def test_bucket_form_on_unit_norm_data_against_the_oracle(monkeypatch):
             assert np.array_equal(st[f], ost[f]), (ef, f)
 
 
+def test_learnt_sizes_are_kept_per_ef():
+    """The launcher sizes a query's scratch from what earlier batches of the same kind (flags, ef) needed.  A caller
+    that alternates between ef values gets each value's learnt configuration back, not a fresh estimate, and the
+    results stay the oracle's throughout."""
+    from hnsw_amd import datagen
+    base = datagen.make("deep", 40000, seed=6)
+    q = datagen.make("deep", 4500, seed=6, stream=1)       # (more than 16 per CU: scratch is sized closely)
+    h = HNSW(16, 16, 100)
+    h.init(96, len(base))
+    h.insert_batch(base, threads=16)
+    idx = oracle.OracleIndex(h.export_flat(), base)
+    settled = {}
+    for ef in (30, 80):
+        for _ in range(3):
+            h.search_batch(q, ef)
+        settled[ef] = h.last_launch_info()
+    assert settled[30]["lds_bytes_per_query"] != settled[80]["lds_bytes_per_query"]
+    for ef in (30, 80, 30, 80):
+        ids, dist, cnt = h.search_batch(q, ef)
+        assert h.last_launch_info() == settled[ef], ef
+        oi, od, oc = idx.search(q, ef, threads=8)
+        assert np.array_equal(cnt, oc)
+        assert_same_results(ids, dist, oi, od, what=f"alternating ef={ef}")
+
+
 @pytest.mark.parametrize("tables", [None, 5])
 def test_bucket_form_spills_to_device_memory(monkeypatch, tables):
     """Tables in LDS sized for far fewer nodes than the queries visit: the overflow table closes and the search
