@@ -50,3 +50,49 @@ def test_kernel_matches_the_reference_binary(tmp_path, kind, build, flags, n, ef
         ids, dist, cnt = h.search_batch(q, ef, flags=flags)
         assert np.array_equal(cnt, r_cnt)
         assert_same_results(ids, dist, r_ids, r_d, what=f"{kind} ef={ef} vs the reference binary")
+
+
+@pytest.mark.parametrize("kind,build,flags,n,efc,efs", [
+    ("sift", "sse", capi.DIST_SSE, 200_000, 100, (10, 50, 150)),
+    ("glove", "scalar", capi.DIST_SCALAR, 30_000, 60, (10,)),
+])
+def test_index_built_and_saved_by_the_reference(tmp_path, kind, build, flags, n, efc, efs):
+    """The other direction: the reference binary BUILDS the index with its own insert and writes it with its own
+    saveGraph; this library reads that file with loadGraph and searches it on the GPU.  Every W_ must equal what the
+    reference returns from the index it built, and the adjacency this library's sequential build makes of the same rows
+    must be the loaded one, list for list — fifty times the size of the committed fixtures."""
+    drv = oracle.ref_driver_path(build)
+    if drv is None:
+        pytest.skip("oracle/_ref is not built (needs the reference sources)")
+    try:
+        subprocess.run([drv], capture_output=True, timeout=20)
+    except OSError:
+        pytest.skip("the reference binary does not run on this host")
+    nq = 300
+    base = datagen.make(kind, n, seed=33)
+    q = datagen.make(kind, nq, seed=33, stream=1)
+    d = base.shape[1]
+    bpath, dpath, gpath, qpath, rpath = (str(tmp_path / x) for x in ("base.bin", "dump.bin", "g.bin", "q.bin", "r.bin"))
+    base.tofile(bpath)
+    q.tofile(qpath)
+    subprocess.run([drv, "build", bpath, str(n), str(d), "16", "16", str(efc), dpath, gpath], check=True, capture_output=True, timeout=300)
+    subprocess.run([drv, "lquery", gpath, "16", "16", str(efc), qpath, str(nq), rpath] + [str(e) for e in efs], check=True,
+                   capture_output=True, timeout=200)
+    ref = oracle.parse_ref_results(rpath)
+    h = HNSW(16, 16, efc)
+    h.loadGraph(gpath)
+    assert h.vector_size_ == d
+    for ef in efs:
+        r_ids, r_d, r_cnt = ref[ef]
+        ids, dist, cnt = h.search_batch(q, ef, flags=flags)
+        assert np.array_equal(cnt, r_cnt)
+        assert_same_results(ids, dist, r_ids, r_d, what=f"{kind} ef={ef}, index built by the reference")
+    if build != "sse":
+        return          # (the host builder implements the shipped SSE-order distance only)
+    # the sequential build of this library on the same rows: the same graph
+    mine = HNSW(16, 16, efc)
+    mine.init(d, n)
+    mine.insert_batch(base, threads=1)
+    a, b = mine.export_flat(), h.export_flat()
+    for name in ("adj0", "up_off", "up_order", "up_down", "up_adj_slot", "up_adj_order", "ep_slot", "ep_order"):
+        assert np.array_equal(getattr(a, name), getattr(b, name)), name
