@@ -111,6 +111,36 @@ int hnsw_amd_insert_batch(hnsw_amd_index* h, const float* rows, uint32_t n, int 
     return guarded([&] { REQUIRE(h && (rows || n == 0), "insert_batch: NULL argument"); h->host.insert_batch(rows, n, threads); });
 }
 
+// Candidate lists for a sub-batch of a GPU-assisted build: bring the device's copy of the graph up to date (all of it
+// when the index grew or is not there yet, lists and upper layers otherwise) and run the batched search on it.
+static void assisted_candidates(void* ctx, const float* queries, uint32_t nq, int ef, uint32_t* ids, float* dist, uint32_t* cnt)
+{
+    hnsw_amd_index* h = static_cast<hnsw_amd_index*>(ctx);
+    const bool same_rows = h->dev.device == h->device && h->dev.g.vectors && h->dev.g.n == h->host.size() && h->dev.g.d == h->host.vector_size_;
+    if (same_rows) h->dev.refresh_graph(h->host);
+    else h->dev.upload(h->host, h->device);
+    const uint32_t flags = HNSW_AMD_DIST_SSE | (h->host.build_float_keys_ ? HNSW_AMD_KEYS_FLOAT : HNSW_AMD_KEYS_INT32);
+    const int rc = hnsw_amd_search_batch(h, queries, nq, ef, (uint32_t)ef, flags, ids, dist, cnt, nullptr);
+    if (rc != HNSW_AMD_OK) throw std::runtime_error(g_err);
+}
+
+int hnsw_amd_insert_batch_assisted(hnsw_amd_index* h, const float* rows, uint32_t n, int threads, int device)
+{
+    return guarded([&] {
+        REQUIRE(h && (rows || n == 0), "insert_batch_assisted: NULL argument");
+        int count = 0;
+        HIP_OK(hipGetDeviceCount(&count));
+        REQUIRE(device >= 0 && device < count, "insert_batch_assisted: no such GPU");
+        h->device = device;
+        h->host.insert_batch(rows, n, threads, assisted_candidates, h);
+        // the device holds every row already: bring its graph to the final state instead of leaving a full upload to
+        // the first search
+        if (h->dev.device == h->device && h->dev.g.vectors && h->dev.g.n == h->host.size() && h->dev.g.d == h->host.vector_size_ &&
+            h->dev.version != h->host.version_)
+            h->dev.refresh_graph(h->host);
+    });
+}
+
 int hnsw_amd_set_build_float_keys(hnsw_amd_index* h, int on)
 {
     return guarded([&] { REQUIRE(h, "set_build_float_keys: index is NULL"); h->host.build_float_keys_ = on != 0; });

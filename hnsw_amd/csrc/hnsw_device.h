@@ -91,6 +91,7 @@ public:
     void release();
     void upload(const HostIndex& h, int device);
     // Builds the quantised byte table (HNSW_AMD_ROWS_Q8) on first use.
+    void refresh_graph(const HostIndex& h);      // lists and upper layers again; vectors stay (same rows)
     void ensure_quantized(const HostIndex& h);
     // Runs the batch (device pointers), re-running overflowed queries on larger tiers.
     // Returns the number of re-run queries; throws on HIP errors / scratch exhaustion.

@@ -422,7 +422,7 @@ void HostIndex::ensure_locks()
     }
 }
 
-void HostIndex::insert_batch(const float* rows, uint32_t n, int threads)
+void HostIndex::insert_batch(const float* rows, uint32_t n, int threads, CandidateSearchFn candidates, void* ctx)
 {
     if (max_node_count_ <= 0) throw std::invalid_argument("insert_batch: init() has not been called");
     if ((int64_t)actual_node_count_ + 1 + n > (int64_t)max_node_count_)
@@ -484,25 +484,58 @@ void HostIndex::insert_batch(const float* rows, uint32_t n, int threads)
             }
             ensure_locks();
             actual_node_count_ = (int)(first + seg_end - 1);
-            std::atomic<uint32_t> cursor{seg_begin};
-            std::vector<std::thread> pool;
-            std::exception_ptr err; std::mutex err_mu;
-            int nt = std::min<int>(threads, 256);
-            for (int t = 0; t < nt; t++) {
-                pool.emplace_back([&]() {
-                    Scratch s;
-                    try {
-                        for (;;) {
-                            uint32_t i = cursor.fetch_add(1);
-                            if (i >= seg_end) break;
-                            uint32_t id = first + i;
-                            insert_one<true>(id, row(id), level[i], slots[i].data(), s);
-                        }
-                    } catch (...) { std::lock_guard<std::mutex> g(err_mu); if (!err) err = std::current_exception(); }
-                });
+            // vectors [lo, hi) of the batch, by a pool of threads; `cand` (optional): for vector lo + j the result list
+            // of a layer-0 search with ef = efConstruction_ run elsewhere, cand_cnt[j] entries at cand_ids/cand_dist + j * ef
+            auto run_range = [&](uint32_t lo, uint32_t hi, const uint32_t* cand_ids, const float* cand_dist, const uint32_t* cand_cnt) {
+                std::atomic<uint32_t> cursor{lo};
+                std::vector<std::thread> pool;
+                std::exception_ptr err; std::mutex err_mu;
+                int nt = std::min<int>(threads, 256);
+                for (int t = 0; t < nt; t++) {
+                    pool.emplace_back([&]() {
+                        Scratch s;
+                        try {
+                            for (;;) {
+                                uint32_t i = cursor.fetch_add(1);
+                                if (i >= hi) break;
+                                uint32_t id = first + i;
+                                const uint32_t j = i - lo;
+                                if (cand_ids && slots[i].size() == 1 && cand_cnt[j] > 0) {
+                                    // a vector that lives in layer 0 only: the reference's insert would run exactly that
+                                    // search (src/hnsw.cpp:241-262); select and link as usual
+                                    const size_t at = (size_t)j * (size_t)efConstruction_;
+                                    s.W.clear();
+                                    for (uint32_t c = 0; c < cand_cnt[j]; c++)
+                                        s.W.push_back(Neighbor{cand_dist[at + c], cand_ids[at + c], cand_ids[at + c]});   // (layer 0: slot = node_order)
+                                    select_neighbors(s.W, s.R, M_, 0);
+                                    link<true>(0, slots[i][0], id, s.R, s);
+                                } else {
+                                    insert_one<true>(id, row(id), level[i], slots[i].data(), s);
+                                }
+                            }
+                        } catch (...) { std::lock_guard<std::mutex> g(err_mu); if (!err) err = std::current_exception(); }
+                    });
+                }
+                for (auto& th : pool) th.join();
+                if (err) std::rethrow_exception(err);
+            };
+            if (!candidates) {
+                run_range(seg_begin, seg_end, nullptr, nullptr, nullptr);
+            } else {
+                // Candidate lists from outside (the GPU): the graph is frozen while a sub-batch is searched, so the vectors
+                // of a sub-batch do not see each other; sub-batches stay below an eighth of what is linked already.
+                std::vector<uint32_t> cids, ccnt; std::vector<float> cdist;
+                for (uint32_t pos = seg_begin; pos < seg_end;) {
+                    const uint32_t linked = first + pos;
+                    const uint32_t want = std::min<uint32_t>(16384u, std::max<uint32_t>(1024u, linked / 16u));
+                    const uint32_t end = std::min<uint32_t>(seg_end, pos + want);
+                    const uint32_t cnt = end - pos;
+                    cids.resize((size_t)cnt * efConstruction_); cdist.resize((size_t)cnt * efConstruction_); ccnt.assign(cnt, 0);
+                    candidates(ctx, row(first + pos), cnt, efConstruction_, cids.data(), cdist.data(), ccnt.data());
+                    run_range(pos, end, cids.data(), cdist.data(), ccnt.data());
+                    pos = end;
+                }
             }
-            for (auto& th : pool) th.join();
-            if (err) std::rethrow_exception(err);
         }
         if (seg_end < n) {
             // the layer-raising vector, alone
@@ -521,7 +554,7 @@ void HostIndex::insert_batch(const float* rows, uint32_t n, int threads)
 // ---------------------------------------------------------------------------------------
 // Flat export / import
 // ---------------------------------------------------------------------------------------
-void HostIndex::export_flat(FlatGraph& g) const
+void HostIndex::export_flat(FlatGraph& g, bool with_layer0) const
 {
     const uint32_t nl = (uint32_t)layers_.size();
     g = FlatGraph();
@@ -529,8 +562,10 @@ void HostIndex::export_flat(FlatGraph& g) const
     if (nl == 0) { g.up_off = {0}; return; }
     const LayerStore& L0 = layers_[0];
     if (L0.count != g.n) throw std::logic_error("export_flat: layer 0 does not hold every vector");
-    g.adj0.assign(L0.nb_order.begin(), L0.nb_order.begin() + (size_t)g.n * g.deg0);
-    g.cnt0.assign(L0.cnt.begin(), L0.cnt.begin() + g.n);
+    if (with_layer0) {
+        g.adj0.assign(L0.nb_order.begin(), L0.nb_order.begin() + (size_t)g.n * g.deg0);
+        g.cnt0.assign(L0.cnt.begin(), L0.cnt.begin() + g.n);
+    }
     g.up_off.assign(nl + 1, 0);
     for (uint32_t l = 1; l < nl; l++) g.up_off[l + 1] = g.up_off[l] + layers_[l].count;
     const uint32_t U = g.up_off[nl];

@@ -68,11 +68,16 @@ public:
 
     void init(uint32_t vector_size, uint32_t max_node_count);
     void insert(const float* q);                                   // sequential, reference-exact
-    void insert_batch(const float* rows, uint32_t n, int threads); // threads > 1: concurrent
+    // Results of layer-0 searches with ef = efConstruction run by someone else (the GPU) on the graph as it stands:
+    // for query j, cnt[j] entries (node_order ascending by distance, and the distances) at ids/dist + j * ef.
+    typedef void (*CandidateSearchFn)(void* ctx, const float* queries, uint32_t nq, int ef, uint32_t* ids, float* dist, uint32_t* cnt);
+    // threads > 1: concurrent.  With `candidates`, vectors that live in layer 0 only take their candidate lists from it
+    // (in sub-batches, between which it sees the graph again) instead of searching on the host.
+    void insert_batch(const float* rows, uint32_t n, int threads, CandidateSearchFn candidates = nullptr, void* ctx = nullptr);
     void save_graph(const char* filename) const;                   // reference file format
     void load_graph(const char* filename);
     void import_flat(const FlatGraph& g, const float* vectors);
-    void export_flat(FlatGraph& g) const;
+    void export_flat(FlatGraph& g, bool with_layer0 = true) const;     // (without: upper layers and entry points only)
     uint32_t size() const { return (uint32_t)(actual_node_count_ + 1); }
     const float* row(uint32_t node_order) const { return vector_data_.data() + (size_t)node_order * vector_size_; }
 

@@ -1396,6 +1396,31 @@ void DeviceIndex::upload(const HostIndex& h, int dev)
     shape_full = BucketShape{}; shape_bulk = BucketShape{};
 }
 
+// The graph of an index whose vectors are on the device already (same rows, same list lengths): the neighbour lists
+// and the upper layers are copied again, nothing else.  The host keeps layer 0's lists in the device's own layout
+// (node_order per slot, 0xFFFFFFFF padding), so that part is one copy.
+void DeviceIndex::refresh_graph(const HostIndex& h)
+{
+    if (device < 0 || !g.vectors) throw std::logic_error("refresh_graph: index not on a device");
+    HIP_CHECK(hipSetDevice(device));
+    FlatGraph fg;
+    h.export_flat(fg, false);
+    if (fg.n != g.n || fg.d != g.d || fg.deg0 != g.deg0 || fg.degu != g.degu || fg.nlayers == 0)
+        throw std::logic_error("refresh_graph: the index changed shape");
+    const std::vector<uint32_t>& lists0 = h.layers_[0].nb_order;
+    if (lists0.size() < (size_t)g.n * g.deg0) throw std::logic_error("refresh_graph: layer 0 is shorter than the index");
+    HIP_CHECK(hipMemcpy(const_cast<uint32_t*>(g.adj0), lists0.data(), (size_t)g.n * g.deg0 * 4, hipMemcpyHostToDevice));
+    for (int b = 2; b <= 5; b++) { if (bufs_[b]) HIP_CHECK(hipFree(bufs_[b])); bufs_[b] = nullptr; }
+    g.nlayers = fg.nlayers;
+    g.top_ep_slot = fg.ep_slot[fg.nlayers - 1]; g.top_ep_order = fg.ep_order[fg.nlayers - 1];
+    g.up_off = to_device(fg.up_off, bufs_[2]);
+    g.up_down = to_device(fg.up_down, bufs_[3]);
+    g.up_adj_slot = to_device(fg.up_adj_slot, bufs_[4]);
+    g.up_adj_order = to_device(fg.up_adj_order, bufs_[5]);
+    HIP_CHECK(hipDeviceSynchronize());
+    version = h.version_;
+}
+
 void DeviceIndex::ensure_quantized(const HostIndex& h)
 {
     if (device < 0) throw std::logic_error("ensure_quantized: index not on a device");

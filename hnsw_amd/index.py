@@ -64,11 +64,16 @@ class HNSW:
         capi.check(capi.lib().hnsw_amd_load_graph(self._h, filename.encode()))
 
     # -- batched / device entry points ---------------------------------------------------
-    def insert_batch(self, rows: np.ndarray, threads: int = 1) -> None:
+    def insert_batch(self, rows: np.ndarray, threads: int = 1, gpu: bool = False) -> None:
+        """threads > 1: concurrent build.  gpu=True: the construction searches of layer-0-only vectors run on the GPU
+        (hnsw_amd_insert_batch_assisted)."""
         rows = np.ascontiguousarray(rows, dtype=np.float32)
         if rows.ndim != 2 or rows.shape[1] != self.vector_size_:
             raise ValueError("insert_batch: rows must be n x vector_size")
-        capi.check(capi.lib().hnsw_amd_insert_batch(self._h, capi.f32(rows), rows.shape[0], threads))
+        if gpu:
+            capi.check(capi.lib().hnsw_amd_insert_batch_assisted(self._h, capi.f32(rows), rows.shape[0], threads, self.device))
+        else:
+            capi.check(capi.lib().hnsw_amd_insert_batch(self._h, capi.f32(rows), rows.shape[0], threads))
 
     def set_build_float_keys(self, on: bool = True) -> None:
         """Construction searches keyed by the float distance (not the reference's int32 truncation): a regular HNSW

@@ -119,6 +119,14 @@ int hnsw_amd_insert(hnsw_amd_index* h, const float* q);
  * sequential inserts; threads > 1: concurrent inserts (a valid HNSW graph of the same
  * construction rule, but not the reference's exact adjacency). */
 int hnsw_amd_insert_batch(hnsw_amd_index* h, const float* rows, uint32_t n, int threads);
+/* The same loop with the construction searches of layer-0-only vectors (19 in 20) run on the GPU: HNSW::insert's
+ * searchLayer(q, efConstruction) (src/hnsw.cpp:246-262) is the query path, so the batched search kernel supplies the
+ * candidate lists of a sub-batch at a time on the graph as it stands (sub-batches of at most an eighth of the linked
+ * nodes, 32768 rows at most), and the host threads run selectNeighbors and the linking (src/hnsw.cpp:263-323,
+ * 1078-1126) as in the concurrent build.  Vectors of one sub-batch do not see each other: a valid HNSW graph of the
+ * same rule, not the reference's exact adjacency.  Needs threads > 1 and n >= 2048 (else: hnsw_amd_insert_batch).
+ * `device`: the GPU that searches (and holds the index afterwards). */
+int hnsw_amd_insert_batch_assisted(hnsw_amd_index* h, const float* rows, uint32_t n, int threads, int device);
 /* Construction option with no counterpart in the reference: key the candidate heap of the searches that insert()
  * runs by the float distance instead of the reference's int32 truncation (src/hnsw.cpp:727,767).  Off by default
  * (the sequential build then reproduces the reference's graph).  On unit-norm data the truncated keys are all 0..3,

@@ -1,0 +1,63 @@
+"""GPU-assisted build: the construction searches of layer-0-only vectors run as batched GPU searches, the host threads
+select and link.  The graph is not the reference's (vectors of one sub-batch do not see each other), so the checks
+are those of any HNSW graph — list invariants, recall against exact ground truth next to the host-only concurrent
+build — plus bit-exact search parity against the oracle ON the graph it built."""
+import time
+
+import numpy as np
+import pytest
+
+from hnsw_amd import HNSW, datagen, harness
+from oracle import oracle
+from tests.helpers import assert_same_results
+
+pytestmark = pytest.mark.gpu
+
+
+def _recall(h, q, gt, ef, k=10):
+    ids, _, _ = h.search_batch(q, ef, out_k=k)
+    return harness.recall_at_k(ids.astype(np.int64), gt, k)
+
+
+@pytest.mark.parametrize("kind,n,d", [("sift", 150_000, 128), ("deep", 60_000, 96)])
+def test_assisted_build_makes_a_graph_as_good_as_the_host_build(kind, n, d):
+    import torch
+    base = datagen.make(kind, n, seed=12)
+    q = datagen.make(kind, 2000, seed=12, stream=1)
+    _, gt, _ = harness.exact_topk_mfma(torch.from_numpy(base).cuda(), torch.from_numpy(q).cuda(), 10)
+    gt = gt.cpu().numpy()
+
+    t0 = time.time()
+    host = HNSW(16, 16, 200)
+    host.init(d, n)
+    host.insert_batch(base, threads=16)
+    t_host = time.time() - t0
+    t0 = time.time()
+    gpu = HNSW(16, 16, 200)
+    gpu.init(d, n)
+    gpu.insert_batch(base, threads=16, gpu=True)
+    t_gpu = time.time() - t0
+    print(f"{kind} {n}: host build {t_host:.1f} s, GPU-assisted {t_gpu:.1f} s")
+
+    g = gpu.export_flat()
+    assert g.n == n
+    adj = g.adj0.reshape(n, g.deg0)
+    cnt = g.cnt0
+    live = np.arange(g.deg0)[None, :] < cnt[:, None]
+    assert (adj[live] < n).all() and (adj[~live] == 0xFFFFFFFF).all()
+    assert cnt.min() >= 1                                            # every vector is linked
+    assert not (adj == np.arange(n, dtype=np.uint32)[:, None]).any()  # no self loops
+    srt = np.sort(np.where(live, adj.astype(np.int64), -1 - np.arange(g.deg0)[None, :]), axis=1)
+    assert (srt[:, 1:] != srt[:, :-1]).all()                          # no duplicate neighbours
+
+    for ef in (20, 50):
+        r_host, r_gpu = _recall(host, q, gt, ef), _recall(gpu, q, gt, ef)
+        print(f"  ef={ef}: recall@10 host build {r_host:.4f}, GPU-assisted {r_gpu:.4f}")
+        assert r_gpu >= r_host - 0.01
+
+    # the search on the graph it built is the oracle's, bit for bit
+    idx = oracle.OracleIndex(g, base)
+    ids, dist, c = gpu.search_batch(q[:300], 40)
+    oi, od, oc = idx.search(q[:300], 40, threads=8)
+    assert np.array_equal(c, oc)
+    assert_same_results(ids, dist, oi, od, what="search on the GPU-assisted graph")
