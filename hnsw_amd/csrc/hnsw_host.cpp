@@ -374,6 +374,9 @@ void HostIndex::insert_one(uint32_t id, const float* q, int level, const uint32_
         else ns = Ls.add_node(id, kPad);
         if (level > L && i == L) top_new_slot = ns;
         s.reset_visited((size_t)max_node_count_);
+        // (concurrent build: another insert may have reached this vector through its node in the layer above and linked to
+        // it already, so the search could arrive at the vector itself — it is not its own neighbour)
+        if (MT) s.test_and_set(id);
         search_layer<MT>(i, q, efConstruction_, s);
         select_neighbors(s.W, s.R, M_, i);
         link<MT>(i, ns, id, s.R, s);
@@ -506,7 +509,8 @@ void HostIndex::insert_batch(const float* rows, uint32_t n, int threads, Candida
                                     const size_t at = (size_t)j * (size_t)efConstruction_;
                                     s.W.clear();
                                     for (uint32_t c = 0; c < cand_cnt[j]; c++)
-                                        s.W.push_back(Neighbor{cand_dist[at + c], cand_ids[at + c], cand_ids[at + c]});   // (layer 0: slot = node_order)
+                                        if (cand_ids[at + c] != id)
+                                            s.W.push_back(Neighbor{cand_dist[at + c], cand_ids[at + c], cand_ids[at + c]});   // (layer 0: slot = node_order)
                                     select_neighbors(s.W, s.R, M_, 0);
                                     link<true>(0, slots[i][0], id, s.R, s);
                                 } else {

@@ -61,3 +61,28 @@ def test_assisted_build_makes_a_graph_as_good_as_the_host_build(kind, n, d):
     oi, od, oc = idx.search(q[:300], 40, threads=8)
     assert np.array_equal(c, oc)
     assert_same_results(ids, dist, oi, od, what="search on the GPU-assisted graph")
+
+
+def test_assisted_build_in_several_calls_and_small_batches():
+    """The index grows over several calls (with searches in between: the device copy is refreshed, not rebuilt from
+    nothing); a call too small for the concurrent path falls back to plain inserts."""
+    import torch
+    n, d = 60_000, 128
+    base = datagen.make("sift", n, seed=14)
+    q = datagen.make("sift", 1000, seed=14, stream=1)
+    h = HNSW(16, 16, 100)
+    h.init(d, n)
+    h.insert_batch(base[:500], threads=16, gpu=True)              # (below 2048 rows: sequential inserts)
+    assert h.actual_node_count_ == 499
+    h.insert_batch(base[500:30_000], threads=16, gpu=True)
+    ids, _, _ = h.search_batch(q, 50, out_k=10)
+    assert ids.max() < 30_000
+    h.insert_batch(base[30_000:], threads=16, gpu=True)
+    assert h.actual_node_count_ == n - 1
+    _, gt, _ = harness.exact_topk_mfma(torch.from_numpy(base).cuda(), torch.from_numpy(q).cuda(), 10)
+    assert _recall(h, q, gt.cpu().numpy(), 50) > 0.97
+    idx = oracle.OracleIndex(h.export_flat(), base)
+    ids, dist, c = h.search_batch(q[:200], 30)
+    oi, od, oc = idx.search(q[:200], 30, threads=8)
+    assert np.array_equal(c, oc)
+    assert_same_results(ids, dist, oi, od, what="after three assisted calls")

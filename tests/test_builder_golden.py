@@ -147,3 +147,26 @@ def test_concurrent_build_leaves_no_more_weakly_linked_nodes_than_the_sequential
     assert c2 <= s2 + 3, (c2, s2)                    # nearly isolated layer-0 nodes
     assert cup <= sup + 3, (cup, sup)                # upper-layer nodes with at most one neighbour
     assert abs(cmean - smean) < 0.2
+
+
+@pytest.mark.parametrize("kind,n", [("deep", 30_000), ("sift", 30_000)])
+def test_concurrent_build_keeps_the_list_invariants(kind, n):
+    """Whatever the interleaving of the inserting threads: ids in range behind a live prefix, padding after it, nobody
+    its own neighbour (an insert that reaches its own vector through links other inserts made first must pass it by),
+    no neighbour twice."""
+    base = datagen.make(kind, n, seed=17)
+    h = HNSW(16, 16, 60)
+    h.init(base.shape[1], n)
+    h.insert_batch(base, threads=8)
+    g = h.export_flat()
+    adj = g.adj0.reshape(n, g.deg0)
+    live = np.arange(g.deg0)[None, :] < g.cnt0[:, None]
+    assert (adj[live] < n).all() and (adj[~live] == 0xFFFFFFFF).all()
+    assert not (adj == np.arange(n, dtype=np.uint32)[:, None]).any()
+    srt = np.sort(np.where(live, adj.astype(np.int64), -1 - np.arange(g.deg0)[None, :]), axis=1)
+    assert (srt[:, 1:] != srt[:, :-1]).all()
+    U = int(g.up_off[g.nlayers])
+    if U:
+        up = g.up_adj_order.reshape(U, g.degu)
+        ulive = np.arange(g.degu)[None, :] < g.up_cnt[:, None]
+        assert not (up == g.up_order[:, None])[ulive].any()
