@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <chrono>
 #include <cstring>
 #include <fstream>
 #include <mutex>
@@ -535,8 +536,14 @@ void HostIndex::insert_batch(const float* rows, uint32_t n, int threads, Candida
                     const uint32_t end = std::min<uint32_t>(seg_end, pos + want);
                     const uint32_t cnt = end - pos;
                     cids.resize((size_t)cnt * efConstruction_); cdist.resize((size_t)cnt * efConstruction_); ccnt.assign(cnt, 0);
+                    const auto t0 = std::chrono::steady_clock::now();
                     candidates(ctx, row(first + pos), cnt, efConstruction_, cids.data(), cdist.data(), ccnt.data());
+                    const auto t1 = std::chrono::steady_clock::now();
                     run_range(pos, end, cids.data(), cdist.data(), ccnt.data());
+                    const auto t2 = std::chrono::steady_clock::now();
+                    assisted_search_s += std::chrono::duration<double>(t1 - t0).count();
+                    assisted_link_s += std::chrono::duration<double>(t2 - t1).count();
+                    assisted_batches++;
                     pos = end;
                 }
             }
@@ -553,6 +560,9 @@ void HostIndex::insert_batch(const float* rows, uint32_t n, int threads, Candida
     }
     actual_node_count_ = (int)(first + n - 1);
     version_++;
+    if (candidates && getenv("HNSW_AMD_VERBOSE"))
+        fprintf(stderr, "[hnsw_amd] assisted build: %u sub-batches so far, %.2f s in candidate searches (graph refresh included), %.2f s selecting and linking\n",
+                assisted_batches, assisted_search_s, assisted_link_s);
 }
 
 // ---------------------------------------------------------------------------------------

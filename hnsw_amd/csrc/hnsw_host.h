@@ -62,6 +62,8 @@ public:
     std::vector<float> vector_data_;   // max_node_count_ x vector_size_, row = node_order
     bool build_float_keys_ = false;    // construction searches keyed by the float distance instead of its int32 truncation
     uint64_t version_ = 0;             // bumped by every mutation (device copy refresh)
+    double assisted_search_s = 0.0, assisted_link_s = 0.0;   // where an assisted build's time went (HNSW_AMD_VERBOSE prints them)
+    uint32_t assisted_batches = 0;
 
     HostIndex(int M, int Mmax, int efConstruction);
     ~HostIndex();
