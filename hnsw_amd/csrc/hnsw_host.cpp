@@ -351,7 +351,8 @@ void HostIndex::link(int layer, uint32_t new_slot, uint32_t id, const std::vecto
 // src/hnsw.cpp:163-334 for the vector with id `id`, level `level`.  new_slots (concurrent
 // path only): the slot reserved for this vector in each layer 0..min(level, top).
 template <bool MT>
-void HostIndex::insert_one(uint32_t id, const float* q, int level, const uint32_t* new_slots, Scratch& s)
+void HostIndex::insert_one(uint32_t id, const float* q, int level, const uint32_t* new_slots, Scratch& s,
+                           const uint32_t* cand_ids, const float* cand_dist, uint32_t cand_cnt)
 {
     const int L = (int)layers_.size() - 1;
     s.reset_visited((size_t)max_node_count_);
@@ -378,7 +379,15 @@ void HostIndex::insert_one(uint32_t id, const float* q, int level, const uint32_
         // (concurrent build: another insert may have reached this vector through its node in the layer above and linked to
         // it already, so the search could arrive at the vector itself — it is not its own neighbour)
         if (MT) s.test_and_set(id);
-        search_layer<MT>(i, q, efConstruction_, s);
+        if (i == 0 && cand_cnt > 0) {
+            // layer 0's candidate list comes from outside (a search from the top of the graph as it stood; the reference
+            // seeds this search with the whole result of the layer above instead, src/hnsw.cpp:246-262)
+            s.W.clear();
+            for (uint32_t c = 0; c < cand_cnt; c++)
+                if (cand_ids[c] != id) s.W.push_back(Neighbor{cand_dist[c], cand_ids[c], cand_ids[c]});      // (layer 0: slot = node_order)
+        } else {
+            search_layer<MT>(i, q, efConstruction_, s);
+        }
         select_neighbors(s.W, s.R, M_, i);
         link<MT>(i, ns, id, s.R, s);
         if (!MT && prev_layer >= 0) layers_[prev_layer].down[prev_slot] = ns;      // (the concurrent path set it in add_node, before any other thread could see the node)
@@ -504,16 +513,19 @@ void HostIndex::insert_batch(const float* rows, uint32_t n, int threads, Candida
                                 if (i >= hi) break;
                                 uint32_t id = first + i;
                                 const uint32_t j = i - lo;
+                                const size_t at = (size_t)j * (size_t)efConstruction_;
                                 if (cand_ids && slots[i].size() == 1 && cand_cnt[j] > 0) {
                                     // a vector that lives in layer 0 only: the reference's insert would run exactly that
                                     // search (src/hnsw.cpp:241-262); select and link as usual
-                                    const size_t at = (size_t)j * (size_t)efConstruction_;
                                     s.W.clear();
                                     for (uint32_t c = 0; c < cand_cnt[j]; c++)
                                         if (cand_ids[at + c] != id)
                                             s.W.push_back(Neighbor{cand_dist[at + c], cand_ids[at + c], cand_ids[at + c]});   // (layer 0: slot = node_order)
                                     select_neighbors(s.W, s.R, M_, 0);
                                     link<true>(0, slots[i][0], id, s.R, s);
+                                } else if (cand_ids) {
+                                    // upper layers on the host (they are small), layer 0 from the same candidate list
+                                    insert_one<true>(id, row(id), level[i], slots[i].data(), s, cand_ids + at, cand_dist + at, cand_cnt[j]);
                                 } else {
                                     insert_one<true>(id, row(id), level[i], slots[i].data(), s);
                                 }

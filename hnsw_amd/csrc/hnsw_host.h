@@ -93,7 +93,8 @@ private:
     void parse_graph_file(const char* filename);
     void validate_loaded(const char* filename) const;
     int draw_level();
-    template <bool MT> void insert_one(uint32_t id, const float* q, int level, const uint32_t* new_slots, Scratch& s);
+    template <bool MT> void insert_one(uint32_t id, const float* q, int level, const uint32_t* new_slots, Scratch& s,
+                                       const uint32_t* cand_ids = nullptr, const float* cand_dist = nullptr, uint32_t cand_cnt = 0);
     template <bool MT> void search_layer_one(int layer, const float* q, Scratch& s);
     template <bool MT> void search_layer(int layer, const float* q, int ef, Scratch& s);
     void select_neighbors(std::vector<Neighbor>& W, std::vector<Neighbor>& R, int M, int layer) const;
