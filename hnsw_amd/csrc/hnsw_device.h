@@ -45,6 +45,7 @@ struct SearchArgs {
     float* out_dist;          // nq x out_k
     uint32_t* out_count;      // nq or nullptr
     hnsw_amd_query_stats* stats;   // nq or nullptr
+    uint32_t mail_off;        // two-wavefront form: dword offset of the wavefronts' mailbox in the query's LDS
     uint32_t known_visit, known_c;   // largest visited set / heap room the launcher already knows of: only queries beyond report
     uint32_t* fail_count;     // device words: [0] number of queries whose scratch overflowed in this launch,
                               // [1] largest visited set, [2] most room the candidate heap was asked for, among the queries
@@ -101,7 +102,7 @@ public:
     // form of the visited set (0: 32-bit slots, 1: 16-bit probing regions, 2: 16-bit bucket regions).
     void last_launch(uint32_t& lds_bytes, uint32_t& resident_per_cu, uint32_t& visited_form) const;
     const void* last_kernel = nullptr;
-    uint32_t last_lds = 0;
+    uint32_t last_lds, last_block = 0;
     int last_form = 0;
     // Diagnostic: milliseconds of one launch in which n_waves wavefronts each read rows_per_wave random rows of the
     // vector table with the search kernel's loads and distance arithmetic and nothing else; `bytes` = what the

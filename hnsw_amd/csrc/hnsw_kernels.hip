@@ -562,7 +562,8 @@ __device__ __forceinline__ void consume_item_scalar(const float* qp, uint32_t e0
 // (already offset to this lane's part), act[s] says whether the lane takes part.  out[s] is
 // valid in every lane of the row's group.  Called by all 64 lanes.  The loads of NBUF items are in
 // flight at any time; with rows of up to 128 dims NBUF = 2 is both sub-batches of an SSE batch.
-template <bool SCALAR, int NBUF, bool IP = false>
+// SUB = 0 / 1: only that sub-batch (the other one is a second wavefront's; SSE order only), -1: both.
+template <bool SCALAR, int NBUF, bool IP = false, int SUB = -1>
 __device__ __forceinline__ void batch_distance(const DistCtx& c, const float* const (&row)[RowMap<SCALAR>::kSub],
                                                const bool (&act)[RowMap<SCALAR>::kSub], float (&out)[RowMap<SCALAR>::kSub], int lane)
 {
@@ -574,14 +575,14 @@ __device__ __forceinline__ void batch_distance(const DistCtx& c, const float* co
     for (int s = 0; s < RM::kSub; s++) acc[s] = 0.0f;
     float4 buf[NBUF][8];
     // item i of the sequence: the sub-batches take turns, item i / kSub of sub-batch i % kSub
-    const uint32_t total = RM::kSub * ni;
+    const uint32_t total = (SUB < 0 ? RM::kSub : 1) * ni;
     auto issue = [&](float4 (&v)[8], uint32_t i) {
-        const uint32_t s = SCALAR ? 0u : (i & 1u), g = SCALAR ? i : (i >> 1);
+        const uint32_t s = SCALAR ? 0u : (SUB < 0 ? (i & 1u) : (uint32_t)SUB), g = (SCALAR || SUB >= 0) ? i : (i >> 1);
         const float* p = (s ? row[RM::kSub - 1] : row[0]) + g * RM::kItemFloats;
         if (s ? act[RM::kSub - 1] : act[0]) { if (g < nf) issue_item<SCALAR, true>(p, 0, v); else issue_item<SCALAR, false>(p, tl, v); }
     };
     auto consume = [&](const float4 (&v)[8], uint32_t i) {
-        const uint32_t s = SCALAR ? 0u : (i & 1u), g = SCALAR ? i : (i >> 1);
+        const uint32_t s = SCALAR ? 0u : (SUB < 0 ? (i & 1u) : (uint32_t)SUB), g = (SCALAR || SUB >= 0) ? i : (i >> 1);
         const float* qp = qs + g * RM::kItemFloats;
         float a = s ? acc[RM::kSub - 1] : acc[0];
         if (s ? act[RM::kSub - 1] : act[0]) {
@@ -659,7 +660,7 @@ __device__ __forceinline__ void batch_distance_u8(const DistCtx& c, const uint8_
 }
 
 // Distances to the rows `id[s]` (sub-batch s; act[s]: the lane's row takes part), from the float or the byte table.
-template <bool SCALAR, int ROWS, int NBUF = 2, bool IP = false>
+template <bool SCALAR, int ROWS, int NBUF = 2, bool IP = false, int SUB = -1>
 __device__ __forceinline__ void rows_distance(const DeviceGraph& g, const DistCtx& c, const uint32_t (&id)[RowMap<SCALAR>::kSub],
                                               const bool (&act)[RowMap<SCALAR>::kSub], float (&out)[RowMap<SCALAR>::kSub], int lane)
 {
@@ -675,7 +676,7 @@ __device__ __forceinline__ void rows_distance(const DeviceGraph& g, const DistCt
         const float* row[RM::kSub];
 #pragma unroll
         for (int s = 0; s < RM::kSub; s++) row[s] = g.vectors + (size_t)id[s] * g.row_stride + (SCALAR ? 0u : 8u * (lane & 3));
-        batch_distance<SCALAR, NBUF, IP>(c, row, act, out, lane);
+        batch_distance<SCALAR, NBUF, IP, SUB>(c, row, act, out, lane);
     }
 }
 
@@ -806,17 +807,59 @@ __device__ __forceinline__ uint32_t w_set_replace_max(uint32_t (&wd)[WR], uint32
 // NBUF: row pieces (8 x 16-byte loads per lane each) in flight during a distance batch.  2 is all a 128-dim row
 //       has to offer; the deep form (6) is for wide rows in a batch too small to fill the chip, where a CU holds
 //       only a few queries, registers are plentiful and nothing but a longer queue of loads hides the memory latency.
+//       The deep form also runs TWO wavefronts per query (workgroups of 128): a row is one serial chain of loads and
+//       fused multiply-adds per lane, a distance batch gives every lane two rows, and the second wavefront takes the
+//       second of them (GIST-shaped 1M x 960, 1000 queries: 0.79 -> 1.06 M queries/s).
 // IP: inner-product metric (distance 1 - q.x) instead of squared L2; float rows, SSE order only.
 // (Except for the deep-prefetch form the kernels are held to 128 registers: four wavefronts per SIMD = 16 queries per CU.
 // The one-lane-per-row kernel for ef > 128 gets 168: it would spill 24 registers at 128, and at those ef the LDS a query
 // needs leaves a CU fewer than 12 queries anyway.)
 template <bool SCALAR, int WR, int ROWS, bool BUCKET, int NBUF, bool IP>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBUF == 2 ? (SCALAR && WR == 4 ? 3 : 4) : 1))) void hnsw_search_kernel(SearchArgs a)
+__global__ __launch_bounds__(NBUF == 2 ? 64 : 128) __attribute__((amdgpu_waves_per_eu(NBUF == 2 ? (SCALAR && WR == 4 ? 3 : 4) : 1))) void hnsw_search_kernel(SearchArgs a)
 {
     typedef RowMap<SCALAR> RM;
     typedef BatchLanes<SCALAR> BL;
     extern __shared__ __align__(16) uint32_t smem[];
-    const int lane = threadIdx.x;
+    // The deep form (wide rows, few queries per CU) runs two wavefronts per query: the first walks the graph and takes the
+    // rows of sub-batch 0 of every distance batch, the second does nothing but the rows of sub-batch 1 — a row is a serial
+    // chain of loads and fused multiply-adds per lane, so halving the rows per lane halves that chain.  They talk through
+    // a mailbox at the end of the query's LDS: [0,64) the batch's ids in merged form, [64,128) its freshness flags,
+    // [128,192) the second wavefront's distances, [192] the command (1 = a batch, 0 = the query is over).
+    constexpr bool kHelper = NBUF != 2;
+    static_assert(!kHelper || (!SCALAR && ROWS == 0), "the two-wavefront form reads float rows in SSE order");
+    const int lane = threadIdx.x & 63;
+    uint32_t* const mail = smem + a.mail_off;
+    if (kHelper && threadIdx.x >= 64) {
+        for (;;) {
+            __syncthreads();                                 // a request (or the end) is in the mailbox
+            if (mail[192] == 0u) break;
+            const uint32_t my = mail[lane];
+            const uint32_t fresh = mail[64 + lane];
+            uint32_t rid[RM::kSub]; bool act[RM::kSub]; float dj[RM::kSub];
+#pragma unroll
+            for (int s = 0; s < RM::kSub; s++) { rid[s] = BL::spread(my, s); act[s] = BL::spread(fresh, s) != 0; }
+            const DistCtx dc = make_dist_ctx<SCALAR>(reinterpret_cast<float*>(smem), a.g.d);
+            rows_distance<SCALAR, ROWS, NBUF, IP, 1>(a.g, dc, rid, act, dj, lane);
+            if ((lane & 3) == 1) mail[128 + lane] = __float_as_uint(dj[RM::kSub - 1]);
+            __syncthreads();                                 // the distances are in the mailbox
+        }
+        return;
+    }
+    // (first wavefront, two-wavefront form) hand sub-batch 1 over, compute sub-batch 0, merge
+    auto batch_with_helper = [&](uint32_t my, bool fresh, const DistCtx& dc) -> float {
+        mail[lane] = my; mail[64 + lane] = fresh ? 1u : 0u;
+        if (lane == 0) mail[192] = 1u;
+        __syncthreads();
+        uint32_t rid[RM::kSub]; bool act[RM::kSub]; float dj[RM::kSub];
+#pragma unroll
+        for (int s = 0; s < RM::kSub; s++) { rid[s] = BL::spread(my, s); act[s] = BL::spread((uint32_t)fresh, s) != 0; }
+        rows_distance<SCALAR, ROWS, NBUF, IP, 0>(a.g, dc, rid, act, dj, lane);
+        __syncthreads();
+        return (lane & 3) == 1 ? __uint_as_float(mail[128 + lane]) : dj[0];
+    };
+    auto release_helper = [&]() {
+        if (kHelper) { if (lane == 0) mail[192] = 0u; __syncthreads(); }
+    };
     const uint32_t mrow = BL::merged_row(lane);
     uint32_t qi = blockIdx.x;
     if (a.qmap) qi = a.qmap[qi];
@@ -905,11 +948,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBUF == 2 ? 
                 st.n_dist += m; nvis += m;
                 LDS_SYNC();
                 if (m == 0) continue;
-                uint32_t rid[RM::kSub]; bool act[RM::kSub]; float dj[RM::kSub];
+                float dm;                                                                      // merged form
+                if constexpr (kHelper) {
+                    dm = batch_with_helper(my_order, fresh, dc);
+                } else {
+                    uint32_t rid[RM::kSub]; bool act[RM::kSub]; float dj[RM::kSub];
 #pragma unroll
-                for (int s = 0; s < RM::kSub; s++) { rid[s] = BL::spread(my_order, s); act[s] = BL::spread((uint32_t)fresh, s) != 0; }
-                rows_distance<SCALAR, ROWS, NBUF, IP>(a.g, dc, rid, act, dj, lane);
-                const float dm = (!SCALAR && (lane & 3) == 1) ? dj[RM::kSub - 1] : dj[0];      // merged form
+                    for (int s = 0; s < RM::kSub; s++) { rid[s] = BL::spread(my_order, s); act[s] = BL::spread((uint32_t)fresh, s) != 0; }
+                    rows_distance<SCALAR, ROWS, NBUF, IP>(a.g, dc, rid, act, dj, lane);
+                    dm = (!SCALAR && (lane & 3) == 1) ? dj[RM::kSub - 1] : dj[0];
+                }
                 const bool mine = fresh && dm == dm;
                 const uint32_t key = mine ? __float_as_uint(dm) : 0x7F800000u;     // non-negative floats order as their bit patterns
                 const uint32_t kmin = wave_min_u32(key);
@@ -999,11 +1047,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBUF == 2 ? 
                 DIAG_STAMP(t2);
                 DIAG_ADD(cy_adj, t1b, t2);
                 if (m != 0) {
-                    uint32_t rid[RM::kSub]; bool act[RM::kSub]; float dj[RM::kSub];
+                    float dm;                                                                  // merged form
+                    if constexpr (kHelper) {
+                        dm = batch_with_helper(my, fresh, dc);
+                    } else {
+                        uint32_t rid[RM::kSub]; bool act[RM::kSub]; float dj[RM::kSub];
 #pragma unroll
-                    for (int s = 0; s < RM::kSub; s++) { rid[s] = BL::spread(my, s); act[s] = BL::spread((uint32_t)fresh, s) != 0; }
-                    rows_distance<SCALAR, ROWS, NBUF, IP>(a.g, dc, rid, act, dj, lane);
-                    const float dm = (!SCALAR && (lane & 3) == 1) ? dj[RM::kSub - 1] : dj[0];      // merged form
+                        for (int s = 0; s < RM::kSub; s++) { rid[s] = BL::spread(my, s); act[s] = BL::spread((uint32_t)fresh, s) != 0; }
+                        rows_distance<SCALAR, ROWS, NBUF, IP>(a.g, dc, rid, act, dj, lane);
+                        dm = (!SCALAR && (lane & 3) == 1) ? dj[RM::kSub - 1] : dj[0];
+                    }
                     DIAG_STAMP(t3);
                     DIAG_ADD(cy_dist, t2, t3);
                     // Admission in list order (src/hnsw.cpp:765-777).  A neighbour that fails
@@ -1094,6 +1147,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBUF == 2 ? 
     st.n_visited0 = nvis;
     DIAG_STAMP(t_l0_end);
 
+    release_helper();                    // (two-wavefront form) no distance batch follows
     if (fail) {
         if (lane == 0) {
             uint32_t at = atomicAdd(a.fail_count, 1u);
@@ -1504,7 +1558,7 @@ void DeviceIndex::last_launch(uint32_t& lds_bytes, uint32_t& resident_per_cu, ui
     if (!last_kernel) return;
     HIP_CHECK(hipSetDevice(device));
     int nb = 0;
-    if (last_lds <= 65536) HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, last_kernel, 64, last_lds));
+    if (last_lds <= 65536) HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, last_kernel, (int)last_block, last_lds));
     else nb = (int)(163840 / last_lds);
     resident_per_cu = (uint32_t)nb;
 }
@@ -1532,7 +1586,7 @@ static SearchKernel pick_rows(bool scalar, int wr, int rows, bool ip)
     return pick_wr<false, 0, BUCKET, 2>(wr);
 }
 
-// deep: the float-row, probing-form kernel with six row pieces in flight (see hnsw_search_kernel)
+// deep: the float-row, probing-form kernel with six row pieces in flight and two wavefronts per query (see hnsw_search_kernel)
 static SearchKernel pick_kernel(bool scalar, int wr, int rows, bool bucket, bool ip, bool deep = false)
 {
     if (deep && !scalar && rows == 0 && !bucket && !ip) return pick_wr<false, 0, false, 6>(wr);
@@ -1730,7 +1784,8 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
         size_t lds = search_lds_bytes(a, std_heap);
         const int wr = std_heap ? 0 : (ef <= 64 ? 1 : (ef <= 128 ? 2 : 4));
         // wide rows in a batch that leaves most of the chip idle: more loads in flight per query
-        const bool deep_rows = g.d > 256 && (uint64_t)a.nq_launch <= 8ull * (uint64_t)num_cus && !getenv("HNSW_AMD_NO_DEEP_ROWS");
+        // (its 240 registers and two wavefronts per query leave a CU four queries: batches of up to four per CU)
+        const bool deep_rows = g.d > 256 && (uint64_t)a.nq_launch <= 4ull * (uint64_t)num_cus && !getenv("HNSW_AMD_NO_DEEP_ROWS");
         const SearchKernel kern_p = pick_kernel(scalar, wr, u8 ? 1 : (q8 ? 2 : 0), false, ip, deep_rows);     // probing forms
         const SearchKernel kern_b = pick_kernel(scalar, wr, u8 ? 1 : (q8 ? 2 : 0), true, ip);      // bucket form
         // LDS a query may use without lowering residency: the float-row kernels need 110-118 VGPRs, i.e. 4 waves per
@@ -1739,6 +1794,10 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
         const uint32_t per_cu = std::min<uint32_t>(16u, (a.nq_launch + (uint32_t)num_cus - 1u) / (uint32_t)num_cus);
         size_t budget = std::min<size_t>(kLdsPerCu / per_cu, 40960);
         if (const char* cap = getenv("HNSW_AMD_LDS_BUDGET")) budget = std::min<size_t>(budget, (size_t)atol(cap));   // tests: bare estimates
+        // (the deep form runs two wavefronts per query, which talk through a mailbox behind the query's tables)
+        constexpr size_t kMailBytes = 1024;
+        const bool deep_kernel = deep_rows && !scalar && !u8 && !q8 && !ip;
+        if (deep_kernel && budget > 4 * kMailBytes) budget -= kMailBytes;
         {
             // 16-bit visited slots where they let a CU hold more queries: the probing form (large regions) or the
             // bucket form (small regions read whole, nearly full, plus an overflow table), whichever needs less LDS.
@@ -1812,6 +1871,14 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
                                     " queries outgrew the largest on-chip scratch configuration (ef too large for LDS?)");
         }
         const SearchKernel kern = a.vis_chunks ? kern_b : kern_p;
+        const bool two_waves = deep_kernel && !a.vis_chunks;
+        const unsigned block_threads = two_waves ? 128u : 64u;
+        a.mail_off = 0;
+        if (two_waves) {
+            a.mail_off = (uint32_t)(lds / 4);
+            lds += kMailBytes;
+            if (lds > (size_t)max_lds) throw std::length_error("search: the query's scratch and the two-wavefront mailbox do not fit the LDS");
+        }
         a.fail_count = cur; a.fail_list = cur + kFailHeader;
         HIP_CHECK(hipMemsetAsync(cur, 0, 4 * kFailHeader, stream));
         h_fail[kFailHeader - 1] = 0xFFFFFFFFu;               // (the report replaces it with the header's zero)
@@ -1820,21 +1887,21 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
         if (const char* pad = getenv("HNSW_AMD_LDS_PAD")) lds += (size_t)atoi(pad);      // occupancy experiments
         if (getenv("HNSW_AMD_VERBOSE")) {
             int nb = 0;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), 64, lds);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), (int)block_threads, lds);
             char form[96];
             if (a.vis_rb == 0xFFFFFFFFu) snprintf(form, sizeof form, "%u slots of 32 bits", a.hash_size);
             else if (a.vis_chunks) snprintf(form, sizeof form, "%u regions x %u slots of 16 bits + %u overflow%s", a.vis_regions, 8u * a.vis_chunks, a.ovf_size,
                                             a.spill_tables ? " + spill tables" : "");
             else snprintf(form, sizeof form, "%u slots of 16 bits in %u regions", a.hash_size, 1u << a.vis_rb);
-            fprintf(stderr, "[hnsw_amd] search launch: %u queries, ef=%d, tier %d (visited: %s for %u ids, C %u), LDS %zu B, resident queries per CU %d\n",
-                    a.nq_launch, ef, tier, form, want_visit, a.cap_c, lds, nb);
+            fprintf(stderr, "[hnsw_amd] search launch: %u queries, ef=%d, tier %d (visited: %s for %u ids, C %u), LDS %zu B, resident queries per CU %d%s\n",
+                    a.nq_launch, ef, tier, form, want_visit, a.cap_c, lds, nb, two_waves ? ", two wavefronts per query" : "");
         }
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         const bool timed = getenv("HNSW_AMD_VERBOSE") != nullptr && sync_and_retry && !no_alloc;
         if (timed) { HIP_CHECK(hipEventCreate(&ev0)); HIP_CHECK(hipEventCreate(&ev1)); HIP_CHECK(hipEventRecord(ev0, stream)); }
-        hipLaunchKernelGGL(kern, dim3(a.nq_launch), dim3(64), lds, stream, a);
+        hipLaunchKernelGGL(kern, dim3(a.nq_launch), dim3(block_threads), lds, stream, a);
         HIP_CHECK(hipGetLastError());
-        if (tier == 0) { last_kernel = reinterpret_cast<const void*>(kern); last_lds = (uint32_t)lds; last_form = a.vis_rb == 0xFFFFFFFFu ? 0 : (a.vis_chunks ? 2 : 1); }
+        if (tier == 0) { last_kernel = reinterpret_cast<const void*>(kern); last_lds = (uint32_t)lds; last_block = block_threads; last_form = a.vis_rb == 0xFFFFFFFFu ? 0 : (a.vis_chunks ? 2 : 1); }
         if (timed) {
             HIP_CHECK(hipEventRecord(ev1, stream));
             HIP_CHECK(hipEventSynchronize(ev1));
