@@ -120,6 +120,30 @@ def test_scratch_overflow_is_retried_transparently(monkeypatch):
     assert_same_results(ids_t.cpu().numpy().view(np.uint32), dist_t.cpu().numpy(), oi, od, what="overflow + re-run")
 
 
+def test_two_wavefront_form_with_overflow_and_rerun(monkeypatch):
+    """Wide rows in a small batch run two wavefronts per query (the second computes half of every distance batch).
+    With the tables held to the bare estimate some queries outgrow them: the first wavefront must let the second one
+    go before it reports the overflow, and the re-run (through the list of overflowed queries) gives the oracle's
+    results and counters."""
+    from hnsw_amd import datagen
+    monkeypatch.setenv("HNSW_AMD_LDS_BUDGET", "1")
+    monkeypatch.setenv("HNSW_AMD_WANT_VISIT", "96")
+    base = datagen.make("gist", 6000, seed=8)
+    q = datagen.make("gist", 150, seed=8, stream=1)
+    h = HNSW(16, 16, 60)
+    h.init(base.shape[1], len(base))
+    h.insert_batch(base, threads=16)
+    idx = oracle.OracleIndex(h.export_flat(), base)
+    for ef in (30, 30, 80):
+        ids, dist, cnt, st = h.search_batch(q, ef, stats=True)
+        oi, od, oc, ost = idx.search(q, ef, stats=True)
+        assert ost["n_visited0"].max() > 200          # the premise: beyond what the first tier was sized for
+        assert np.array_equal(cnt, oc)
+        assert_same_results(ids, dist, oi, od, what=f"two wavefronts, ef={ef}")
+        for f in st.dtype.names:
+            assert np.array_equal(st[f], ost[f]), (ef, f)
+
+
 def test_search_argument_errors():
     h = HNSW(16, 16, 200)
     h.init(8, 10)
