@@ -322,7 +322,8 @@ public:
             for (size_t j = 0; j < d; j++) rows[i * d + j] *= inv;
         }
     }
-    void create(const char* filename, const char* datasetname, int threads = 1, bool normalize = false)
+    // (gpu_build: the construction searches run on GPU `device`, see insertBatchGpu)
+    void create(const char* filename, const char* datasetname, int threads = 1, bool normalize = false, bool gpu_build = false, int device = 0)
     {
         hsize_t dims[2] = {0, 0};
         hdfReader::getDimensions(filename, datasetname, &dims);
@@ -332,7 +333,8 @@ public:
         std::vector<float> data((size_t)dims[0] * dims[1]);
         hdfReader::readData(filename, datasetname, data.data());
         if (normalize) normalizeRows(data.data(), (size_t)dims[0], (size_t)dims[1]);
-        insertBatch(data.data(), (uint32_t)dims[0], threads);       // (keeps layers_ current when mirror_layers is set)
+        if (gpu_build) insertBatchGpu(data.data(), (uint32_t)dims[0], threads, device);
+        else insertBatch(data.data(), (uint32_t)dims[0], threads);       // (keeps layers_ current when mirror_layers is set)
     }
     double query(const char* filename, const char* querydatasetname, const char* resultdatasetname, int ef, bool normalize = false)
     {
