@@ -473,21 +473,22 @@ __device__ __forceinline__ DistCtx make_dist_ctx(const float* qs, uint32_t d)
 }
 
 // SSE mode: the lane's 2 x 16 bytes of each of 4 lines.  Scalar mode: one whole line.
-template <bool SCALAR, bool FULL>
+// NLD: the loads a full item consists of (8, or fewer in a kernel built for one row shape)
+template <bool SCALAR, bool FULL, int NLD = 8>
 __device__ __forceinline__ void issue_item(const float* p, uint32_t nld, float4 (&v)[8])
 {
 #pragma unroll
-    for (int t = 0; t < 8; t++)
+    for (int t = 0; t < NLD; t++)
         if (FULL || (uint32_t)t < nld) v[t] = *reinterpret_cast<const float4*>(p + (SCALAR ? 4 * t : 32 * (t >> 1) + 4 * (t & 1)));
 }
 
 // SSE order, lane j of the row's quad: p / qp point at this lane's 8 floats of the item's first line.
 // IP: the chain accumulates the products q_i * x_i instead of the squared differences (inner-product metric).
-template <bool FULL, bool IP>
+template <bool FULL, bool IP, int NLD = 8>
 __device__ __forceinline__ void consume_item_sse(const float* qp, uint32_t nld, const float4 (&v)[8], float& a)
 {
 #pragma unroll
-    for (int t = 0; t < 8; t++)
+    for (int t = 0; t < NLD; t++)
         if (FULL || (uint32_t)t < nld) {
             const float4 q = *reinterpret_cast<const float4*>(qp + 32 * (t >> 1) + 4 * (t & 1));
             if constexpr (IP) {
@@ -495,11 +496,11 @@ __device__ __forceinline__ void consume_item_sse(const float* qp, uint32_t nld, 
                 a = __builtin_fmaf(v[t].z, q.z, a); a = __builtin_fmaf(v[t].w, q.w, a);
                 continue;
             }
-            // the differences two at a time (packed f32 subtract: same IEEE result per element); the chain itself is serial
-            typedef float f2 __attribute__((ext_vector_type(2)));
-            const f2 dlo = f2{v[t].x, v[t].y} - f2{q.x, q.y}, dhi = f2{v[t].z, v[t].w} - f2{q.z, q.w};
-            a = __builtin_fmaf(dlo.x, dlo.x, a); a = __builtin_fmaf(dlo.y, dlo.y, a);
-            a = __builtin_fmaf(dhi.x, dhi.x, a); a = __builtin_fmaf(dhi.y, dhi.y, a);
+            // (plain subtracts and fused multiply-adds: the packed two-element f32 instructions cost several times the
+            // issue time of the two plain ones they replace on this chip; the file is built with -fno-slp-vectorize)
+            const float dx = v[t].x - q.x, dy = v[t].y - q.y, dz = v[t].z - q.z, dw = v[t].w - q.w;
+            a = __builtin_fmaf(dx, dx, a); a = __builtin_fmaf(dy, dy, a);
+            a = __builtin_fmaf(dz, dz, a); a = __builtin_fmaf(dw, dw, a);
         }
 }
 
@@ -521,11 +522,10 @@ __device__ __forceinline__ void consume_item_u8(const float* qp, uint32_t nwords
         if (FULL || (uint32_t)w < nwords) {
             const float4 q = *reinterpret_cast<const float4*>(qp + 4 * w);
             const uint32_t word = u4_get(v[w >> 2], w & 3);
-            typedef float f2 __attribute__((ext_vector_type(2)));
-            const f2 dlo = f2{(float)(word & 0xFFu), (float)((word >> 8) & 0xFFu)} - f2{q.x, q.y};
-            const f2 dhi = f2{(float)((word >> 16) & 0xFFu), (float)(word >> 24)} - f2{q.z, q.w};
-            a = __builtin_fmaf(dlo.x, dlo.x, a); a = __builtin_fmaf(dlo.y, dlo.y, a);
-            a = __builtin_fmaf(dhi.x, dhi.x, a); a = __builtin_fmaf(dhi.y, dhi.y, a);
+            const float dx = (float)(word & 0xFFu) - q.x, dy = (float)((word >> 8) & 0xFFu) - q.y;
+            const float dz = (float)((word >> 16) & 0xFFu) - q.z, dw = (float)(word >> 24) - q.w;
+            a = __builtin_fmaf(dx, dx, a); a = __builtin_fmaf(dy, dy, a);
+            a = __builtin_fmaf(dz, dz, a); a = __builtin_fmaf(dw, dw, a);
         }
 }
 
@@ -563,23 +563,30 @@ __device__ __forceinline__ void consume_item_scalar(const float* qp, uint32_t e0
 // valid in every lane of the row's group.  Called by all 64 lanes.  The loads of NBUF items are in
 // flight at any time; with rows of up to 128 dims NBUF = 2 is both sub-batches of an SSE batch.
 // SUB = 0 / 1: only that sub-batch (the other one is a second wavefront's; SSE order only), -1: both.
-template <bool SCALAR, int NBUF, bool IP = false, int SUB = -1>
+// NL: 0, or the number of 16-byte loads per lane that make up a row when the kernel is built for that one row shape
+// (8: 128 dims, 6: 96 dims).
+template <bool SCALAR, int NBUF, bool IP = false, int SUB = -1, int NL = 0>
 __device__ __forceinline__ void batch_distance(const DistCtx& c, const float* const (&row)[RowMap<SCALAR>::kSub],
                                                const bool (&act)[RowMap<SCALAR>::kSub], float (&out)[RowMap<SCALAR>::kSub], int lane)
 {
     typedef RowMap<SCALAR> RM;
-    const uint32_t ni = c.nitems, nf = c.nfull, tl = c.tail_loads;
+    // (a kernel built for one row shape: one item of NL loads, known at compile time, so the loops below unroll into
+    // straight-line code without a test per load)
+    static_assert(NL == 0 || (!SCALAR && NBUF == 2 && SUB < 0), "row-shape kernels read float rows in SSE order, one wavefront per query");
+    constexpr int NLD = NL ? NL : 8;
+    const uint32_t ni = NL ? 1u : c.nitems, nf = NL ? 1u : c.nfull, tl = NL ? 0u : c.tail_loads;
     const float* qs = c.qs + (SCALAR ? 0 : 8 * (lane & 3));
     float acc[RM::kSub];
 #pragma unroll
     for (int s = 0; s < RM::kSub; s++) acc[s] = 0.0f;
+    {
     float4 buf[NBUF][8];
     // item i of the sequence: the sub-batches take turns, item i / kSub of sub-batch i % kSub
     const uint32_t total = (SUB < 0 ? RM::kSub : 1) * ni;
     auto issue = [&](float4 (&v)[8], uint32_t i) {
         const uint32_t s = SCALAR ? 0u : (SUB < 0 ? (i & 1u) : (uint32_t)SUB), g = (SCALAR || SUB >= 0) ? i : (i >> 1);
         const float* p = (s ? row[RM::kSub - 1] : row[0]) + g * RM::kItemFloats;
-        if (s ? act[RM::kSub - 1] : act[0]) { if (g < nf) issue_item<SCALAR, true>(p, 0, v); else issue_item<SCALAR, false>(p, tl, v); }
+        if (s ? act[RM::kSub - 1] : act[0]) { if (NL || g < nf) issue_item<SCALAR, true, NLD>(p, 0, v); else issue_item<SCALAR, false>(p, tl, v); }
     };
     auto consume = [&](const float4 (&v)[8], uint32_t i) {
         const uint32_t s = SCALAR ? 0u : (SUB < 0 ? (i & 1u) : (uint32_t)SUB), g = (SCALAR || SUB >= 0) ? i : (i >> 1);
@@ -587,7 +594,7 @@ __device__ __forceinline__ void batch_distance(const DistCtx& c, const float* co
         float a = s ? acc[RM::kSub - 1] : acc[0];
         if (s ? act[RM::kSub - 1] : act[0]) {
             if (SCALAR) { if (g < nf) consume_item_scalar<true>(qp, 0, 0, v, a); else consume_item_scalar<false>(qp, g * RM::kItemFloats, c.d4, v, a); }
-            else { if (g < nf) consume_item_sse<true, IP>(qp, 0, v, a); else consume_item_sse<false, IP>(qp, tl, v, a); }
+            else { if (NL || g < nf) consume_item_sse<true, IP, NLD>(qp, 0, v, a); else consume_item_sse<false, IP>(qp, tl, v, a); }
         }
         if (s) acc[RM::kSub - 1] = a; else acc[0] = a;
     };
@@ -604,6 +611,7 @@ __device__ __forceinline__ void batch_distance(const DistCtx& c, const float* co
                 consume(buf[b], i + b);
                 if (i + b + NBUF < total) issue(buf[b], i + b + NBUF);
             }
+    }
     }
 #pragma unroll
     for (int s = 0; s < RM::kSub; s++) {
@@ -660,7 +668,7 @@ __device__ __forceinline__ void batch_distance_u8(const DistCtx& c, const uint8_
 }
 
 // Distances to the rows `id[s]` (sub-batch s; act[s]: the lane's row takes part), from the float or the byte table.
-template <bool SCALAR, int ROWS, int NBUF = 2, bool IP = false, int SUB = -1>
+template <bool SCALAR, int ROWS, int NBUF = 2, bool IP = false, int SUB = -1, int NL = 0>
 __device__ __forceinline__ void rows_distance(const DeviceGraph& g, const DistCtx& c, const uint32_t (&id)[RowMap<SCALAR>::kSub],
                                               const bool (&act)[RowMap<SCALAR>::kSub], float (&out)[RowMap<SCALAR>::kSub], int lane)
 {
@@ -676,7 +684,7 @@ __device__ __forceinline__ void rows_distance(const DeviceGraph& g, const DistCt
         const float* row[RM::kSub];
 #pragma unroll
         for (int s = 0; s < RM::kSub; s++) row[s] = g.vectors + (size_t)id[s] * g.row_stride + (SCALAR ? 0u : 8u * (lane & 3));
-        batch_distance<SCALAR, NBUF, IP, SUB>(c, row, act, out, lane);
+        batch_distance<SCALAR, NBUF, IP, SUB, NL>(c, row, act, out, lane);
     }
 }
 
@@ -814,8 +822,10 @@ __device__ __forceinline__ uint32_t w_set_replace_max(uint32_t (&wd)[WR], uint32
 // (Except for the deep-prefetch form the kernels are held to 128 registers: four wavefronts per SIMD = 16 queries per CU.
 // The one-lane-per-row kernel for ef > 128 gets 168: it would spill 24 registers at 128, and at those ef the LDS a query
 // needs leaves a CU fewer than 12 queries anyway.)
-template <bool SCALAR, int WR, int ROWS, bool BUCKET, int NBUF, bool IP>
-__global__ __launch_bounds__(NBUF == 2 ? 64 : 128) __attribute__((amdgpu_waves_per_eu(NBUF == 2 ? (SCALAR && WR == 4 ? 3 : 4) : 1))) void hnsw_search_kernel(SearchArgs a)
+// NL: 0 = rows of any length; 8 / 6 = a kernel for rows of exactly 128 / 96 used dims (float rows, SSE order), whose
+//     distance batches are straight-line code.
+template <bool SCALAR, int WR, int ROWS, bool BUCKET, int NBUF, bool IP, int NL>
+__global__ __launch_bounds__(NBUF == 2 ? 64 : 128) __attribute__((amdgpu_waves_per_eu(NBUF == 2 ? (SCALAR && WR == 4 ? 3 : 4) : 1, NBUF == 2 ? (SCALAR && WR == 4 ? 3 : 4) : 1))) void hnsw_search_kernel(SearchArgs a)
 {
     typedef RowMap<SCALAR> RM;
     typedef BatchLanes<SCALAR> BL;
@@ -916,7 +926,7 @@ __global__ __launch_bounds__(NBUF == 2 ? 64 : 128) __attribute__((amdgpu_waves_p
         uint32_t rid[RM::kSub]; bool act[RM::kSub]; float dj[RM::kSub];
 #pragma unroll
         for (int s = 0; s < RM::kSub; s++) { rid[s] = cur_id; act[s] = s == 0 && lane < RM::kLanesPerRow; }
-        rows_distance<SCALAR, ROWS, NBUF, IP>(a.g, dc, rid, act, dj, lane);
+        rows_distance<SCALAR, ROWS, NBUF, IP, -1, NL>(a.g, dc, rid, act, dj, lane);
         cur_dist = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(dj[0]), 0));
     }
     st.n_dist = 1;
@@ -955,7 +965,7 @@ __global__ __launch_bounds__(NBUF == 2 ? 64 : 128) __attribute__((amdgpu_waves_p
                     uint32_t rid[RM::kSub]; bool act[RM::kSub]; float dj[RM::kSub];
 #pragma unroll
                     for (int s = 0; s < RM::kSub; s++) { rid[s] = BL::spread(my_order, s); act[s] = BL::spread((uint32_t)fresh, s) != 0; }
-                    rows_distance<SCALAR, ROWS, NBUF, IP>(a.g, dc, rid, act, dj, lane);
+                    rows_distance<SCALAR, ROWS, NBUF, IP, -1, NL>(a.g, dc, rid, act, dj, lane);
                     dm = (!SCALAR && (lane & 3) == 1) ? dj[RM::kSub - 1] : dj[0];
                 }
                 const bool mine = fresh && dm == dm;
@@ -1054,7 +1064,7 @@ __global__ __launch_bounds__(NBUF == 2 ? 64 : 128) __attribute__((amdgpu_waves_p
                         uint32_t rid[RM::kSub]; bool act[RM::kSub]; float dj[RM::kSub];
 #pragma unroll
                         for (int s = 0; s < RM::kSub; s++) { rid[s] = BL::spread(my, s); act[s] = BL::spread((uint32_t)fresh, s) != 0; }
-                        rows_distance<SCALAR, ROWS, NBUF, IP>(a.g, dc, rid, act, dj, lane);
+                        rows_distance<SCALAR, ROWS, NBUF, IP, -1, NL>(a.g, dc, rid, act, dj, lane);
                         dm = (!SCALAR && (lane & 3) == 1) ? dj[RM::kSub - 1] : dj[0];
                     }
                     DIAG_STAMP(t3);
@@ -1280,6 +1290,7 @@ __global__ __launch_bounds__(NBUF == 2 ? 64 : 128) __attribute__((amdgpu_waves_p
 // vector table with the search kernel's own loads and arithmetic (rows_distance: four lanes per row, 32 rows
 // in flight), but with no heaps, no visited set, no neighbour lists and no dependence of one batch on the
 // previous one.  Residency is set the way the search kernel's is, by the dynamic LDS size.
+template <int NL>
 __global__ __launch_bounds__(64) void gather_ceiling_kernel(DeviceGraph g, uint32_t iters, float* __restrict__ out)
 {
     extern __shared__ __align__(16) uint32_t smem[];
@@ -1297,7 +1308,7 @@ __global__ __launch_bounds__(64) void gather_ceiling_kernel(DeviceGraph g, uint3
         uint32_t rid[2]; float dj[2];
         rid[0] = __umulhi(mix(seed + it * 32u + 2u * r), g.n);
         rid[1] = __umulhi(mix(seed + it * 32u + 2u * r + 1u), g.n);
-        rows_distance<false, 0, 2>(g, dc, rid, act, dj, lane);
+        rows_distance<false, 0, 2, false, -1, NL>(g, dc, rid, act, dj, lane);
         acc += dj[0] + dj[1];
     }
     if (lane == 0) out[blockIdx.x] = acc;
@@ -1349,6 +1360,10 @@ __global__ void store_rows_q8_kernel(const float* __restrict__ src, uint8_t* __r
 }
 
 }  // namespace
+
+// Rows of exactly 128 or 96 used dims (the SSE loop uses the first 16 * floor(d / 16)) have kernels of their own whose
+// distance batches are straight-line code; 0 = the kernel for any row length.
+static int row_shape_loads(uint32_t d) { const uint32_t d_eff = d & ~15u; return d_eff == 128u ? 8 : (d_eff == 96u ? 6 : 0); }
 
 size_t search_lds_bytes(const SearchArgs& a, bool w_in_lds)
 {
@@ -1531,11 +1546,15 @@ float DeviceIndex::gather_ceiling(uint32_t n_waves, uint32_t rows_per_wave, uint
     hipEvent_t e0 = nullptr, e1 = nullptr;
     float ms = 0.0f;
     try {
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gather_ceiling_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        // (the same row-shape kernels the search uses)
+        typedef void (*CeilingKernel)(DeviceGraph, uint32_t, float*);
+        const int nl = row_shape_loads(g.d);
+        const CeilingKernel ck = nl == 8 ? gather_ceiling_kernel<8> : (nl == 6 ? gather_ceiling_kernel<6> : gather_ceiling_kernel<0>);
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ck), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
         HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
-        hipLaunchKernelGGL(gather_ceiling_kernel, dim3(n_waves), dim3(64), lds, stream, g, iters, d_out);       // warm-up
+        hipLaunchKernelGGL(ck, dim3(n_waves), dim3(64), lds, stream, g, iters, d_out);       // warm-up
         HIP_CHECK(hipEventRecord(e0, stream));
-        for (int rep = 0; rep < 3; rep++) hipLaunchKernelGGL(gather_ceiling_kernel, dim3(n_waves), dim3(64), lds, stream, g, iters, d_out);
+        for (int rep = 0; rep < 3; rep++) hipLaunchKernelGGL(ck, dim3(n_waves), dim3(64), lds, stream, g, iters, d_out);
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipEventRecord(e1, stream));
         HIP_CHECK(hipEventSynchronize(e1));
@@ -1565,32 +1584,35 @@ void DeviceIndex::last_launch(uint32_t& lds_bytes, uint32_t& resident_per_cu, ui
 
 typedef void (*SearchKernel)(SearchArgs);
 
-template <bool SCALAR, int ROWS, bool BUCKET, int NBUF, bool IP = false>
+template <bool SCALAR, int ROWS, bool BUCKET, int NBUF, bool IP = false, int NL = 0>
 static SearchKernel pick_wr(int wr)
 {
     switch (wr) {
-        case 0: return hnsw_search_kernel<SCALAR, 0, ROWS, BUCKET, NBUF, IP>;
-        case 1: return hnsw_search_kernel<SCALAR, 1, ROWS, BUCKET, NBUF, IP>;
-        case 2: return hnsw_search_kernel<SCALAR, 2, ROWS, BUCKET, NBUF, IP>;
-        default: return hnsw_search_kernel<SCALAR, 4, ROWS, BUCKET, NBUF, IP>;
+        case 0: return hnsw_search_kernel<SCALAR, 0, ROWS, BUCKET, NBUF, IP, NL>;
+        case 1: return hnsw_search_kernel<SCALAR, 1, ROWS, BUCKET, NBUF, IP, NL>;
+        case 2: return hnsw_search_kernel<SCALAR, 2, ROWS, BUCKET, NBUF, IP, NL>;
+        default: return hnsw_search_kernel<SCALAR, 4, ROWS, BUCKET, NBUF, IP, NL>;
     }
 }
 
 template <bool BUCKET>
-static SearchKernel pick_rows(bool scalar, int wr, int rows, bool ip)
+static SearchKernel pick_rows(bool scalar, int wr, int rows, bool ip, int nl)
 {
     if (ip) return pick_wr<false, 0, BUCKET, 2, true>(wr);
     if (scalar) return pick_wr<true, 0, BUCKET, 2>(wr);
     if (rows == 1) return pick_wr<false, 1, BUCKET, 2>(wr);
     if (rows == 2) return pick_wr<false, 2, BUCKET, 2>(wr);
+    if (nl == 8) return pick_wr<false, 0, BUCKET, 2, false, 8>(wr);
+    if (nl == 6) return pick_wr<false, 0, BUCKET, 2, false, 6>(wr);
     return pick_wr<false, 0, BUCKET, 2>(wr);
 }
 
 // deep: the float-row, probing-form kernel with six row pieces in flight and two wavefronts per query (see hnsw_search_kernel)
-static SearchKernel pick_kernel(bool scalar, int wr, int rows, bool bucket, bool ip, bool deep = false)
+static SearchKernel pick_kernel(bool scalar, int wr, int rows, bool bucket, bool ip, uint32_t d, bool deep = false)
 {
     if (deep && !scalar && rows == 0 && !bucket && !ip) return pick_wr<false, 0, false, 6>(wr);
-    return bucket ? pick_rows<true>(scalar, wr, rows, ip) : pick_rows<false>(scalar, wr, rows, ip);
+    const int nl = getenv("HNSW_AMD_GENERIC_ROWS") ? 0 : row_shape_loads(d);       // (diagnostics: the kernel for any row length)
+    return bucket ? pick_rows<true>(scalar, wr, rows, ip, nl) : pick_rows<false>(scalar, wr, rows, ip, nl);
 }
 
 constexpr size_t kLdsPerCu = 163840;     // gfx950: 160 KB
@@ -1786,8 +1808,8 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
         // wide rows in a batch that leaves most of the chip idle: more loads in flight per query
         // (its 240 registers and two wavefronts per query leave a CU four queries: batches of up to four per CU)
         const bool deep_rows = g.d > 256 && (uint64_t)a.nq_launch <= 4ull * (uint64_t)num_cus && !getenv("HNSW_AMD_NO_DEEP_ROWS");
-        const SearchKernel kern_p = pick_kernel(scalar, wr, u8 ? 1 : (q8 ? 2 : 0), false, ip, deep_rows);     // probing forms
-        const SearchKernel kern_b = pick_kernel(scalar, wr, u8 ? 1 : (q8 ? 2 : 0), true, ip);      // bucket form
+        const SearchKernel kern_p = pick_kernel(scalar, wr, u8 ? 1 : (q8 ? 2 : 0), false, ip, g.d, deep_rows);     // probing forms
+        const SearchKernel kern_b = pick_kernel(scalar, wr, u8 ? 1 : (q8 ? 2 : 0), true, ip, g.d);      // bucket form
         // LDS a query may use without lowering residency: the float-row kernels need 110-118 VGPRs, i.e. 4 waves per
         // SIMD = 16 one-wave workgroups per CU (the byte-row kernels could run 24, measured no faster than 16), and a
         // batch of fewer than 16 queries per CU needs even fewer slots (bounded, so that clearing the tables stays cheap).

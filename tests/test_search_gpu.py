@@ -53,6 +53,27 @@ def test_kernel_matches_oracle_with_counters(name, keys, w):
             assert np.array_equal(st[field], ost[field]), f"{name} ef={ef}: counter {field} differs"
 
 
+@pytest.mark.parametrize("name", ["int_d128_n4000", "unit_d100_n2000_sse"])
+def test_row_shape_kernels_equal_the_kernel_for_any_row_length(name, monkeypatch):
+    """Rows of 128 and 96 used dims (d = 100 under the SSE loop) run kernels built for that shape; the kernel for any
+    row length (HNSW_AMD_GENERIC_ROWS) must give the same W_ and the same counters, and both the reference's."""
+    g = Golden(name)
+    h = HNSW(*g.meta["ctor"])
+    h.import_flat(g.graph, g.base)
+    for ef in (10, 50, 100, 200):
+        monkeypatch.delenv("HNSW_AMD_GENERIC_ROWS", raising=False)
+        ids, dist, cnt, st = h.search_batch(g.queries, ef, flags=_flags(g), stats=True)
+        monkeypatch.setenv("HNSW_AMD_GENERIC_ROWS", "1")
+        ids2, dist2, cnt2, st2 = h.search_batch(g.queries, ef, flags=_flags(g), stats=True)
+        assert np.array_equal(ids, ids2) and np.array_equal(dist, dist2) and np.array_equal(cnt, cnt2)
+        for field in st.dtype.names:
+            assert np.array_equal(st[field], st2[field]), f"{name} ef={ef}: counter {field} differs"
+        if ef in g.results:
+            ids_ref, dist_ref, cnt_ref = g.results[ef]
+            assert np.array_equal(cnt, cnt_ref)
+            assert_same_results(ids, dist, ids_ref, dist_ref, what=f"{name} ef={ef}")
+
+
 def test_top_k_is_a_prefix_of_W():
     g = Golden("int_d128_n4000")
     h = HNSW(*g.meta["ctor"])
