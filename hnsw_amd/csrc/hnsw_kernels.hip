@@ -482,15 +482,31 @@ __device__ __forceinline__ void issue_item(const float* p, uint32_t nld, float4 
         if (FULL || (uint32_t)t < nld) v[t] = *reinterpret_cast<const float4*>(p + (SCALAR ? 4 * t : 32 * (t >> 1) + 4 * (t & 1)));
 }
 
+// A kernel built for one row shape keeps the lane's pieces of the query in registers for the whole search (all six
+// of a 96-dim row; the first four of a 128-dim row, whose kernels have less room), so that a distance batch does not
+// wait for them to come out of LDS piece by piece.
+template <int NL>
+struct QRegs {
+    static constexpr int K = NL == 6 ? 6 : (NL == 8 ? 4 : 0);
+    float4 q[K ? K : 1];
+};
+template <int NL>
+__device__ __forceinline__ void qregs_load(QRegs<NL>& qr, const float* qs, int lane)
+{
+#pragma unroll
+    for (int t = 0; t < QRegs<NL>::K; t++) qr.q[t] = *reinterpret_cast<const float4*>(qs + 8 * (lane & 3) + 32 * (t >> 1) + 4 * (t & 1));
+}
+
 // SSE order, lane j of the row's quad: p / qp point at this lane's 8 floats of the item's first line.
 // IP: the chain accumulates the products q_i * x_i instead of the squared differences (inner-product metric).
-template <bool FULL, bool IP, int NLD = 8>
-__device__ __forceinline__ void consume_item_sse(const float* qp, uint32_t nld, const float4 (&v)[8], float& a)
+// QK: the first QK pieces of the query come from registers (qk), the others from LDS.
+template <bool FULL, bool IP, int NLD = 8, int QK = 0>
+__device__ __forceinline__ void consume_item_sse(const float* qp, uint32_t nld, const float4 (&v)[8], float& a, const float4 (&qk)[QK ? QK : 1])
 {
 #pragma unroll
     for (int t = 0; t < NLD; t++)
         if (FULL || (uint32_t)t < nld) {
-            const float4 q = *reinterpret_cast<const float4*>(qp + 32 * (t >> 1) + 4 * (t & 1));
+            const float4 q = t < QK ? qk[t] : *reinterpret_cast<const float4*>(qp + 32 * (t >> 1) + 4 * (t & 1));
             if constexpr (IP) {
                 a = __builtin_fmaf(v[t].x, q.x, a); a = __builtin_fmaf(v[t].y, q.y, a);
                 a = __builtin_fmaf(v[t].z, q.z, a); a = __builtin_fmaf(v[t].w, q.w, a);
@@ -567,7 +583,8 @@ __device__ __forceinline__ void consume_item_scalar(const float* qp, uint32_t e0
 // (8: 128 dims, 6: 96 dims).
 template <bool SCALAR, int NBUF, bool IP = false, int SUB = -1, int NL = 0>
 __device__ __forceinline__ void batch_distance(const DistCtx& c, const float* const (&row)[RowMap<SCALAR>::kSub],
-                                               const bool (&act)[RowMap<SCALAR>::kSub], float (&out)[RowMap<SCALAR>::kSub], int lane)
+                                               const bool (&act)[RowMap<SCALAR>::kSub], float (&out)[RowMap<SCALAR>::kSub], int lane,
+                                               const QRegs<NL>& qr = QRegs<NL>())
 {
     typedef RowMap<SCALAR> RM;
     // (a kernel built for one row shape: one item of NL loads, known at compile time, so the loops below unroll into
@@ -594,7 +611,7 @@ __device__ __forceinline__ void batch_distance(const DistCtx& c, const float* co
         float a = s ? acc[RM::kSub - 1] : acc[0];
         if (s ? act[RM::kSub - 1] : act[0]) {
             if (SCALAR) { if (g < nf) consume_item_scalar<true>(qp, 0, 0, v, a); else consume_item_scalar<false>(qp, g * RM::kItemFloats, c.d4, v, a); }
-            else { if (NL || g < nf) consume_item_sse<true, IP, NLD>(qp, 0, v, a); else consume_item_sse<false, IP>(qp, tl, v, a); }
+            else { if (NL || g < nf) consume_item_sse<true, IP, NLD, QRegs<NL>::K>(qp, 0, v, a, qr.q); else consume_item_sse<false, IP>(qp, tl, v, a, QRegs<0>().q); }
         }
         if (s) acc[RM::kSub - 1] = a; else acc[0] = a;
     };
@@ -670,7 +687,8 @@ __device__ __forceinline__ void batch_distance_u8(const DistCtx& c, const uint8_
 // Distances to the rows `id[s]` (sub-batch s; act[s]: the lane's row takes part), from the float or the byte table.
 template <bool SCALAR, int ROWS, int NBUF = 2, bool IP = false, int SUB = -1, int NL = 0>
 __device__ __forceinline__ void rows_distance(const DeviceGraph& g, const DistCtx& c, const uint32_t (&id)[RowMap<SCALAR>::kSub],
-                                              const bool (&act)[RowMap<SCALAR>::kSub], float (&out)[RowMap<SCALAR>::kSub], int lane)
+                                              const bool (&act)[RowMap<SCALAR>::kSub], float (&out)[RowMap<SCALAR>::kSub], int lane,
+                                              const QRegs<NL>& qr = QRegs<NL>())
 {
     typedef RowMap<SCALAR> RM;
     if constexpr (ROWS != 0) {
@@ -684,7 +702,7 @@ __device__ __forceinline__ void rows_distance(const DeviceGraph& g, const DistCt
         const float* row[RM::kSub];
 #pragma unroll
         for (int s = 0; s < RM::kSub; s++) row[s] = g.vectors + (size_t)id[s] * g.row_stride + (SCALAR ? 0u : 8u * (lane & 3));
-        batch_distance<SCALAR, NBUF, IP, SUB, NL>(c, row, act, out, lane);
+        batch_distance<SCALAR, NBUF, IP, SUB, NL>(c, row, act, out, lane, qr);
     }
 }
 
@@ -908,6 +926,8 @@ __global__ __launch_bounds__(NBUF == 2 ? 64 : 128) __attribute__((amdgpu_waves_p
         for (uint32_t i = lane; i < hash_words; i += 64) hash[i] = kEmpty;
     }
     LDS_SYNC();
+    QRegs<NL> qr;
+    qregs_load(qr, qs, lane);
 
     hnsw_amd_query_stats st = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t fail = 0;
@@ -926,7 +946,7 @@ __global__ __launch_bounds__(NBUF == 2 ? 64 : 128) __attribute__((amdgpu_waves_p
         uint32_t rid[RM::kSub]; bool act[RM::kSub]; float dj[RM::kSub];
 #pragma unroll
         for (int s = 0; s < RM::kSub; s++) { rid[s] = cur_id; act[s] = s == 0 && lane < RM::kLanesPerRow; }
-        rows_distance<SCALAR, ROWS, NBUF, IP, -1, NL>(a.g, dc, rid, act, dj, lane);
+        rows_distance<SCALAR, ROWS, NBUF, IP, -1, NL>(a.g, dc, rid, act, dj, lane, qr);
         cur_dist = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(dj[0]), 0));
     }
     st.n_dist = 1;
@@ -965,7 +985,7 @@ __global__ __launch_bounds__(NBUF == 2 ? 64 : 128) __attribute__((amdgpu_waves_p
                     uint32_t rid[RM::kSub]; bool act[RM::kSub]; float dj[RM::kSub];
 #pragma unroll
                     for (int s = 0; s < RM::kSub; s++) { rid[s] = BL::spread(my_order, s); act[s] = BL::spread((uint32_t)fresh, s) != 0; }
-                    rows_distance<SCALAR, ROWS, NBUF, IP, -1, NL>(a.g, dc, rid, act, dj, lane);
+                    rows_distance<SCALAR, ROWS, NBUF, IP, -1, NL>(a.g, dc, rid, act, dj, lane, qr);
                     dm = (!SCALAR && (lane & 3) == 1) ? dj[RM::kSub - 1] : dj[0];
                 }
                 const bool mine = fresh && dm == dm;
@@ -1064,7 +1084,7 @@ __global__ __launch_bounds__(NBUF == 2 ? 64 : 128) __attribute__((amdgpu_waves_p
                         uint32_t rid[RM::kSub]; bool act[RM::kSub]; float dj[RM::kSub];
 #pragma unroll
                         for (int s = 0; s < RM::kSub; s++) { rid[s] = BL::spread(my, s); act[s] = BL::spread((uint32_t)fresh, s) != 0; }
-                        rows_distance<SCALAR, ROWS, NBUF, IP, -1, NL>(a.g, dc, rid, act, dj, lane);
+                        rows_distance<SCALAR, ROWS, NBUF, IP, -1, NL>(a.g, dc, rid, act, dj, lane, qr);
                         dm = (!SCALAR && (lane & 3) == 1) ? dj[RM::kSub - 1] : dj[0];
                     }
                     DIAG_STAMP(t3);
@@ -1300,6 +1320,8 @@ __global__ __launch_bounds__(64) void gather_ceiling_kernel(DeviceGraph g, uint3
     for (uint32_t i = lane; i < qpad; i += 64) qs[i] = 0.0f;
     LDS_SYNC();
     const DistCtx dc = make_dist_ctx<false>(qs, g.d);
+    QRegs<NL> qr;
+    qregs_load(qr, qs, lane);
     auto mix = [](uint32_t x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x; };
     const uint32_t seed = blockIdx.x * 2654435761u + 12345u, r = (uint32_t)lane >> 2;
     const bool act[2] = {true, true};
@@ -1308,7 +1330,7 @@ __global__ __launch_bounds__(64) void gather_ceiling_kernel(DeviceGraph g, uint3
         uint32_t rid[2]; float dj[2];
         rid[0] = __umulhi(mix(seed + it * 32u + 2u * r), g.n);
         rid[1] = __umulhi(mix(seed + it * 32u + 2u * r + 1u), g.n);
-        rows_distance<false, 0, 2, false, -1, NL>(g, dc, rid, act, dj, lane);
+        rows_distance<false, 0, 2, false, -1, NL>(g, dc, rid, act, dj, lane, qr);
         acc += dj[0] + dj[1];
     }
     if (lane == 0) out[blockIdx.x] = acc;
