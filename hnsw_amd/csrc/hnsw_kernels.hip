@@ -116,15 +116,16 @@ struct COrder {   // comp(a,b) = a.key > b.key
 
 // Minimum of an unsigned value over the 64 lanes with DPP moves (no LDS round trips):
 // within quads, half rows and rows, then across the four rows; the result is read from lane 63.
+// (Lanes a step does not write take all ones, the identity of the minimum: each step is one v_min_u32 with a DPP operand.)
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t x)
 {
     uint32_t y;
-    y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0xB1, 0xF, 0xF, false); x = x < y ? x : y;
-    y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x4E, 0xF, 0xF, false); x = x < y ? x : y;
-    y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x141, 0xF, 0xF, false); x = x < y ? x : y;
-    y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x140, 0xF, 0xF, false); x = x < y ? x : y;
-    y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x142, 0xA, 0xF, false); x = x < y ? x : y;
-    y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x143, 0xC, 0xF, false); x = x < y ? x : y;
+    y = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, 0xB1, 0xF, 0xF, false); x = x < y ? x : y;
+    y = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, 0x4E, 0xF, 0xF, false); x = x < y ? x : y;
+    y = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, 0x141, 0xF, 0xF, false); x = x < y ? x : y;
+    y = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, 0x140, 0xF, 0xF, false); x = x < y ? x : y;
+    y = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, 0x142, 0xA, 0xF, false); x = x < y ? x : y;
+    y = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, 0x143, 0xC, 0xF, false); x = x < y ? x : y;
     return __builtin_amdgcn_readlane(x, 63);
 }
 
@@ -769,16 +770,17 @@ __device__ __forceinline__ uint32_t w_entry_dist(const uint32_t (&wd)[WR], uint3
     return v;
 }
 
-// Maximum of an unsigned value over the 64 lanes (same DPP steps as wave_min_u32).
+// Maximum of an unsigned value over the 64 lanes (same DPP steps as wave_min_u32).  The lanes a step does not write
+// take 0, the identity of the maximum, so that every step can be one v_max_u32 with a DPP operand.
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t x)
 {
     uint32_t y;
-    y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0xB1, 0xF, 0xF, false); x = x > y ? x : y;
-    y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x4E, 0xF, 0xF, false); x = x > y ? x : y;
-    y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x141, 0xF, 0xF, false); x = x > y ? x : y;
-    y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x140, 0xF, 0xF, false); x = x > y ? x : y;
-    y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x142, 0xA, 0xF, false); x = x > y ? x : y;
-    y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x143, 0xC, 0xF, false); x = x > y ? x : y;
+    y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, false); x = x > y ? x : y;
+    y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, false); x = x > y ? x : y;
+    y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xF, 0xF, false); x = x > y ? x : y;
+    y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xF, 0xF, false); x = x > y ? x : y;
+    y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false); x = x > y ? x : y;
+    y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false); x = x > y ? x : y;
     return __builtin_amdgcn_readlane(x, 63);
 }
 
@@ -795,21 +797,22 @@ __device__ __forceinline__ void w_set_append(uint32_t (&wd)[WR], uint32_t (&wi)[
         if (64u * w + (uint32_t)lane == slot) { wd[w] = db; wi[w] = id; }
 }
 
-// Replaces one entry whose distance bits are `fb` (the current maximum; W holds `n` entries) and returns the new maximum.
+// Replaces one entry whose distance bits are `fb` (the current maximum of a full W) and returns the new maximum.
+// Straight-line: one comparison per register, the first register that holds `fb` and the first such lane in it are
+// picked with scalar arithmetic, and every lane selects between its old entry and the new one.  (`fb` is never 0
+// here - nothing is admitted below a maximum of 0 - so the unused slots past the end of W, which hold 0, never match.)
 template <int WR>
-__device__ __forceinline__ uint32_t w_set_replace_max(uint32_t (&wd)[WR], uint32_t (&wi)[WR], uint32_t n, uint32_t fb, uint32_t db, uint32_t id, int lane)
+__device__ __forceinline__ uint32_t w_set_replace_max(uint32_t (&wd)[WR], uint32_t (&wi)[WR], uint32_t fb, uint32_t db, uint32_t id, int lane)
 {
-    bool done = false;
+    bool found = false;                                       // wave-uniform
 #pragma unroll
     for (int w = 0; w < WR; w++) {
-        if (done) continue;                                   // wave-uniform
-        const uint32_t left = n > 64u * w ? n - 64u * w : 0u;
-        const unsigned long long valid = left >= 64u ? ~0ull : (1ull << left) - 1ull;
-        const unsigned long long b = __ballot(wd[w] == fb) & valid;
-        if (b) {
-            if (lane == __builtin_ctzll(b)) { wd[w] = db; wi[w] = id; }
-            done = true;
-        }
+        const unsigned long long b = __ballot(wd[w] == fb);
+        const bool here = !found && b != 0ull;
+        const bool mine = here && lane == __builtin_ctzll(b | (1ull << 63));
+        wd[w] = mine ? db : wd[w];
+        wi[w] = mine ? id : wi[w];
+        found = found || b != 0ull;
     }
     uint32_t m = wd[0];
 #pragma unroll
@@ -1109,7 +1112,7 @@ __global__ __launch_bounds__(NBUF == 2 ? 64 : 128) __attribute__((amdgpu_waves_p
                                 nC++;
                                 const uint2 anc = heap_push_read<COrder>(C, nC, lane);      // in flight during the insert into W
                                 if constexpr (WR >= 2) {
-                                    f = __uint_as_float(w_set_replace_max<(WR > 0 ? WR : 1)>(wd, wi, ef, __float_as_uint(f), db, id, lane));
+                                    f = __uint_as_float(w_set_replace_max<(WR > 0 ? WR : 1)>(wd, wi, __float_as_uint(f), db, id, lane));
                                 } else {
                                     w_sorted_insert<(WR > 0 ? WR : 1)>(wd, wi, ef, db, id, lane);
                                     f = __uint_as_float(w_entry_dist<(WR > 0 ? WR : 1)>(wd, ef - 1));
@@ -1137,7 +1140,7 @@ __global__ __launch_bounds__(NBUF == 2 ? 64 : 128) __attribute__((amdgpu_waves_p
                                         nW++;
                                         f = dist > f ? dist : f;          // (the largest distance in W, as W_.front() of the reference's heap)
                                     } else {
-                                        f = __uint_as_float(w_set_replace_max<(WR > 0 ? WR : 1)>(wd, wi, ef, __float_as_uint(f), we.x, we.y, lane));
+                                        f = __uint_as_float(w_set_replace_max<(WR > 0 ? WR : 1)>(wd, wi, __float_as_uint(f), we.x, we.y, lane));
                                     }
                                 } else {
                                     w_sorted_insert<(WR > 0 ? WR : 1)>(wd, wi, nW, we.x, we.y, lane);
