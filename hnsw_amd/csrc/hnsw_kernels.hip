@@ -102,9 +102,9 @@ __device__ __forceinline__ float rflf(float v) { return __uint_as_float(__builti
 //    comp(ancestor, value); lane k owns ancestor k, one ballot gives the climb length.
 //  - pop: __adjust_heap first walks the hole from the root to a leaf choosing, at every
 //    node, a child by comparing the two SIBLINGS only (never the moving value), so every
-//    node's choice can be evaluated at once (one ballot per 64 internal nodes) and the
-//    walk becomes bit tests; then the saved last element climbs back up that same path
-//    (again one ballot).  Lane k owns step k of the path.
+//    node's choice can be evaluated at once (lane i of a register holds the child node i hands
+//    the hole to) and the walk becomes one lane read per level; then the saved last element
+//    climbs back up that same path (one ballot).  Lane k owns step k of the path.
 // Both are called with wave-uniform arguments by all 64 lanes.
 // ---------------------------------------------------------------------------------------
 struct WOrder {   // comp(a,b) = a.dist < b.dist
@@ -163,32 +163,44 @@ __device__ __forceinline__ uint2 heap_pop_wave(uint2* a, uint32_t n /* size befo
     const uint32_t len = n - 1;
     const uint2 v = a[len];
     const uint32_t nint = (len - 1) >> 1;      // nodes with both children inside [0, len)
-    // bit i of the masks: node i hands the hole to its LEFT child (comp(right, left)); nodes 0..255, i.e. the
-    // first eight levels, are decided at once
-    const uint32_t nint1 = nint < 256u ? nint : 256u;
-    unsigned long long m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+    const uint32_t nint1 = nint < 256u ? nint : 256u;      // nodes 0..255, the first eight levels, are decided at once
+    // Every node of the first eight levels decides at once which child the hole moves to (node 64b + lane in register
+    // b): next = 2i + 2 - comp(right, left).  The reads of the first two registers (heaps of up to 258 entries) are
+    // issued together without a test, those of the other two under one.  (Nodes past nint1 read node 0's children;
+    // the walk never looks at their entries.)
+    uint32_t ch0, ch1, ch2 = 0, ch3 = 0;
     {
-        // (every lane reads; nodes past nint1 read node 0's children and are masked out)
-        auto sibling_mask = [&](uint32_t base) -> unsigned long long {
+        auto children = [&](uint32_t base, uint2& r, uint2& l) {
             const uint32_t i = base + (uint32_t)lane, ic = i < nint1 ? i : 0u;
-            const uint32_t left = nint1 - base;                  // > 0 where this is called
-            const unsigned long long valid = left >= 64u ? ~0ull : (1ull << left) - 1ull;
-            return __ballot(Ord::before(a[2 * ic + 2], a[2 * ic + 1])) & valid;
+            r = a[2 * ic + 2]; l = a[2 * ic + 1];
         };
-        if (nint1 > 0)   m0 = sibling_mask(0);
-        if (nint1 > 64)  m1 = sibling_mask(64);
-        if (nint1 > 128) m2 = sibling_mask(128);
-        if (nint1 > 192) m3 = sibling_mask(192);
+        auto next_of = [&](uint32_t base, const uint2& r, const uint2& l) -> uint32_t {
+            return 2u * (base + (uint32_t)lane) + 2u - (Ord::before(r, l) ? 1u : 0u);
+        };
+        uint2 r0, l0, r1, l1;
+        children(0, r0, l0);
+        children(64, r1, l1);
+        ch0 = next_of(0, r0, l0);
+        ch1 = next_of(64, r1, l1);
+        if (nint1 > 128) {
+            uint2 r2, l2, r3, l3;
+            children(128, r2, l2);
+            children(192, r3, l3);
+            ch2 = next_of(128, r2, l2);
+            ch3 = next_of(192, r3, l3);
+        }
     }
-    // Walk the hole down on the scalar unit, in 1-based indices: the children of p are 2p (left) and
-    // 2p+1 (right), so the path is the bit string of the final index and step k of it is a shift.
+    // Walk the hole down: one lane read per level (the index of the node the hole is at selects the lane).
     uint32_t idx = 0;                                         // 0-based node the hole is at
     {
-        const uint32_t lim0 = nint1 < 63u ? nint1 : 63u;     // nodes 0..62 (six levels) are all in m0
-        while (idx < lim0) idx = 2 * idx + 2 - (uint32_t)((m0 >> idx) & 1ull);
-        while (idx < nint1) {
-            const unsigned long long m = idx < 64 ? m0 : (idx < 128 ? m1 : (idx < 192 ? m2 : m3));
-            idx = 2 * idx + 2 - (uint32_t)((m >> (idx & 63u)) & 1ull);
+        const uint32_t lim0 = nint1 < 64u ? nint1 : 64u;     // nodes 0..63 are in ch0
+        while (idx < lim0) idx = __builtin_amdgcn_readlane(ch0, idx);
+        while (idx < nint1) {                                // (at most three steps: nodes 64..255 are levels 6 and 7)
+            const uint32_t blk = idx >> 6;
+            uint32_t t = ch1;                                // the register is picked with two selects, not with branches
+            t = blk >= 2u ? ch2 : t;
+            t = blk >= 3u ? ch3 : t;
+            idx = __builtin_amdgcn_readlane(t, idx & 63u);
         }
         // a heap of more than 513 entries: the levels below the eighth, one LDS round trip each
         while (idx < nint) {
