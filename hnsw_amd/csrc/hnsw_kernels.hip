@@ -858,7 +858,7 @@ __device__ __forceinline__ uint32_t w_set_replace_max(uint32_t (&wd)[WR], uint32
 // NL: 0 = rows of any length; 8 / 6 = a kernel for rows of exactly 128 / 96 used dims (float rows, SSE order), whose
 //     distance batches are straight-line code.
 template <bool SCALAR, int WR, int ROWS, bool BUCKET, int NBUF, bool IP, int NL>
-__global__ __launch_bounds__(NBUF == 2 ? 64 : 128) __attribute__((amdgpu_waves_per_eu(NBUF == 2 ? (SCALAR && WR == 4 ? 3 : 4) : 1, NBUF == 2 ? (SCALAR && WR == 4 ? 3 : 4) : 1))) void hnsw_search_kernel(SearchArgs a)
+__global__ __launch_bounds__(NBUF == 2 ? 64 : 128) __attribute__((amdgpu_waves_per_eu(NBUF == 2 ? (SCALAR && WR == 4 ? 3 : 4) : 1, NBUF == 2 ? (SCALAR && WR == 4 ? 3 : 4) : 2))) void hnsw_search_kernel(SearchArgs a)
 {
     typedef RowMap<SCALAR> RM;
     typedef BatchLanes<SCALAR> BL;
