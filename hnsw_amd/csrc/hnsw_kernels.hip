@@ -334,24 +334,26 @@ __device__ __forceinline__ bool visited_insert_bucket(uint32_t* hash, uint32_t r
     const uint32_t tt = tag * 0x00010001u;
     // a half-word of x = w ^ tt is zero where the slot holds the tag; (x - 0x00010001) & ~x & 0x80008000 is
     // non-zero exactly when some half-word of x is zero
+    // All four chunks a region can have are read at once, whatever the region's size (the reads past a region's end
+    // land in the next region or in the overflow table behind the last one, and are ignored): one LDS round trip
+    // instead of one per chunk, and no branch on the chunk count.
     uint32_t z = 0, last = 0;
     LDS_SYNC();
+    const uint4 vc[4] = {reg[0], reg[1], reg[2], reg[3]};
 #pragma unroll
-    for (uint32_t c = 0; c < 4; c++)
-        if (c < nchunk) {
-            const uint4 v = reg[c];
-            uint32_t x;
-            x = v.x ^ tt; z |= (x - 0x00010001u) & ~x;
-            x = v.y ^ tt; z |= (x - 0x00010001u) & ~x;
-            x = v.z ^ tt; z |= (x - 0x00010001u) & ~x;
-            if (c + 1 == nchunk) {
-                last = v.w;
-                x = (v.w ^ tt) | 0x80000000u;        // the upper half is the count, not a tag
-            } else {
-                x = v.w ^ tt;
-            }
-            z |= (x - 0x00010001u) & ~x;
-        }
+    for (uint32_t c = 0; c < 4; c++) {
+        const uint4 v = vc[c];
+        const bool used = c < 2u || c < nchunk;                 // (a region has at least two chunks)
+        const bool is_last = c >= 1u && c + 1u == nchunk;
+        uint32_t x, zc = 0;
+        x = v.x ^ tt; zc |= (x - 0x00010001u) & ~x;
+        x = v.y ^ tt; zc |= (x - 0x00010001u) & ~x;
+        x = v.z ^ tt; zc |= (x - 0x00010001u) & ~x;
+        x = (v.w ^ tt) | (is_last ? 0x80000000u : 0u);          // the upper half of the last word is the count, not a tag
+        zc |= (x - 0x00010001u) & ~x;
+        z |= used ? zc : 0u;
+        last = is_last ? v.w : last;
+    }
     const bool hit = (z & 0x80008000u) != 0u;
     uint32_t count = ((last >> 16) + 1u) & 0xFFFFu;
     bool fresh = false, full = false, done = hit;
