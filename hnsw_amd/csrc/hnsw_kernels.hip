@@ -88,7 +88,7 @@ __device__ __forceinline__ int32_t trunc_key(float f)
 // (Loads of lists and rows are left as generic loads on purpose.  Giving them the device address space lets the
 // compiler wait for exactly the loads it needs, but also lets it move them past the LDS work they were placed in
 // front of, and the overlap written into the code — a neighbour list requested before the heap is repaired, rows
-// requested before the query is read — is lost: measured 40 % slower on the one-lane-per-row path and 9 % at ef=20.)
+// requested before the query is read — is lost: measured 9 % slower at ef=20 and 40 % on an earlier form of the scalar-order path.)
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ float rflf(float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); }
 
@@ -446,15 +446,18 @@ __host__ __device__ __forceinline__ uint32_t stored_pos_u8(uint32_t dim)
 //    every line (2 x 16 B) and nothing is exchanged until the final ((s0+s1)+s2)+s3.  A load
 //    instruction covers 16 rows x 64 bytes, so a line is touched by 2 instructions.  A list is
 //    handled 32 rows at a time as two sub-batches of 16 whose loads are in flight together.
-//  SCALAR=true (the -DNO_MANUAL_VECTORIZATION build, src/hnsw.h:387-400): one running sum per
-//    row, so one lane per row reads whole lines; 64 rows per batch.
+//  SCALAR=true (the -DNO_MANUAL_VECTORIZATION build, src/hnsw.h:387-400): one running sum per row over all dims
+//    in index order.  The same four lanes read the same bytes (coalesced 64-byte pieces, every line touched by two
+//    instructions instead of eight); dim 4k + j of a line is lane j's k-th element, so the running sum visits the
+//    lanes of the quad in turn: it travels as a rotating DPP operand (consume_item_scalar), one add per dim per wave
+//    instruction for 16 rows at once.
 template <bool SCALAR>
 struct RowMap {
-    static constexpr int kLanesPerRow = SCALAR ? 1 : 4;
-    static constexpr int kSub = SCALAR ? 1 : 2;                   // sub-batches in flight
+    static constexpr int kLanesPerRow = 4;
+    static constexpr int kSub = 2;                                // sub-batches in flight
     static constexpr int kRowsPerSub = 64 / kLanesPerRow;
     static constexpr int kRowsPerBatch = kSub * kRowsPerSub;
-    static constexpr int kItemFloats = SCALAR ? 32 : 128;         // dims one "item" (8 x 16-byte loads per lane) covers
+    static constexpr int kItemFloats = 128;                       // dims one "item" (8 x 16-byte loads per lane) covers
 };
 
 struct DistCtx {
@@ -463,6 +466,7 @@ struct DistCtx {
     uint32_t nitems;        // nfull (+1 when tail_loads > 0)
     uint32_t tail_loads;    // 16-byte loads per lane of the last, partial item
     uint32_t d4;            // scalar mode: dims whose square is rounded before the add
+    uint32_t kf;            // scalar mode: element index (dim / 4) of the fused group of the last d % 4 dims, or all ones
 };
 
 template <bool SCALAR>
@@ -471,13 +475,12 @@ __device__ __forceinline__ DistCtx make_dist_ctx(const float* qs, uint32_t d)
     DistCtx c;
     c.qs = qs;
     c.d4 = d & ~3u;
+    c.kf = (d & 3u) ? (c.d4 >> 2) : 0xFFFFFFFFu;
     if (SCALAR) {
-        // every dim takes part; an item is one line, always loaded whole (rows and query are
-        // zero padded, and adding the square of 0 changes nothing); only lines entirely below
-        // d4 are free of the fused tail
-        const uint32_t lines = (d + 31u) >> 5;
-        c.nfull = c.d4 >> 5;
-        c.tail_loads = lines > c.nfull ? 8u : 0u;
+        // every dim takes part; the last item is loaded in whole 16-dim pieces (rows and query are zero padded, and
+        // adding the square of 0 changes nothing); only items entirely below d4 are free of the fused tail
+        c.nfull = c.d4 >> 7;
+        c.tail_loads = (d - 128u * c.nfull + 15u) >> 4;
     } else {
         const uint32_t d_eff = d & ~15u;          // the SSE loop drops the last d mod 16 dims
         c.nfull = d_eff >> 7;
@@ -487,14 +490,14 @@ __device__ __forceinline__ DistCtx make_dist_ctx(const float* qs, uint32_t d)
     return c;
 }
 
-// SSE mode: the lane's 2 x 16 bytes of each of 4 lines.  Scalar mode: one whole line.
+// The lane's 2 x 16 bytes of each of 4 lines.
 // NLD: the loads a full item consists of (8, or fewer in a kernel built for one row shape)
 template <bool SCALAR, bool FULL, int NLD = 8>
 __device__ __forceinline__ void issue_item(const float* p, uint32_t nld, float4 (&v)[8])
 {
 #pragma unroll
     for (int t = 0; t < NLD; t++)
-        if (FULL || (uint32_t)t < nld) v[t] = *reinterpret_cast<const float4*>(p + (SCALAR ? 4 * t : 32 * (t >> 1) + 4 * (t & 1)));
+        if (FULL || (uint32_t)t < nld) v[t] = *reinterpret_cast<const float4*>(p + 32 * (t >> 1) + 4 * (t & 1));
 }
 
 // A kernel built for one row shape keeps the lane's pieces of the query in registers for the whole search (all six
@@ -502,7 +505,7 @@ __device__ __forceinline__ void issue_item(const float* p, uint32_t nld, float4 
 // wait for them to come out of LDS piece by piece.
 template <int NL>
 struct QRegs {
-    static constexpr int K = NL == 6 ? 6 : (NL == 8 ? 4 : 0);
+    static constexpr int K = NL == 6 ? 6 : (NL == 8 ? 4 : 0);       // (the scalar-order kernels, NL = 7, read the query from LDS)
     float4 q[K ? K : 1];
 };
 template <int NL>
@@ -562,38 +565,42 @@ __device__ __forceinline__ void consume_item_u8(const float* qp, uint32_t nwords
 
 __device__ __forceinline__ float f4_get(const float4& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
 
-// Scalar order: one line (8 loads, laid out [j][k]) consumed in dim order 4k+j; squares are rounded
-// before the add for dims below d4 and fused for the last d%4 (what g++ 11 emits for that loop).
-template <bool FULL>
-__device__ __forceinline__ void consume_item_scalar(const float* qp, uint32_t e0, uint32_t d4, const float4 (&v)[8], float& a)
+// Scalar order over the four lanes of a row: the running sum of the reference's plain loop visits the dims in index
+// order, and dim 4k + j of a line is the k-th element of lane j.  `x` is the rotating sum: every wave instruction
+// `x = x(from the lane before, in the quad) + mine` advances the chain by one dim in the lane whose turn it is (the
+// other three lanes compute values that are overwritten before anybody reads them), so after the four
+// instructions of element k the sum over dims .. 4k+3 sits in lane 3, where lane 0 picks it up for element k+1.
+// Squares are rounded before the add for dims below d4 and fused for the last d % 4 (what g++ 11 emits for that loop):
+// `kf` is the element index (dim / 4, counted over the whole row) of that fused group, or all ones when d % 4 == 0;
+// its unused lanes hold padding zeros, which leave the sum as it is either way.
+__device__ __forceinline__ float quad_from_previous_lane(float x)
 {
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-        float4 q[4];                       // the query's elements k = 4h..4h+3 of each sum j
-#pragma unroll
-        for (int j = 0; j < 4; j++) q[j] = *reinterpret_cast<const float4*>(qp + 8 * j + 4 * h);
-#pragma unroll
-        for (int kk = 0; kk < 4; kk++) {
-            const int k = 4 * h + kk;
-            float tj[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) tj[j] = f4_get(v[2 * j + h], kk) - f4_get(q[j], kk);
-            if (FULL || e0 + 4 * k < d4) {
-#pragma unroll
-                for (int j = 0; j < 4; j++) { const float sq = tj[j] * tj[j]; a = a + sq; }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; j++) a = __builtin_fmaf(tj[j], tj[j], a);
-            }
-        }
-    }
+    return __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(x), 0x93, 0xF, 0xF, false));   // quad_perm [3,0,1,2]
 }
 
-// Distances from the query to up to kSub rows per lane group: row[s] points at the stored row
-// (already offset to this lane's part), act[s] says whether the lane takes part.  out[s] is
-// valid in every lane of the row's group.  Called by all 64 lanes.  The loads of NBUF items are in
-// flight at any time; with rows of up to 128 dims NBUF = 2 is both sub-batches of an SSE batch.
-// SUB = 0 / 1: only that sub-batch (the other one is a second wavefront's; SSE order only), -1: both.
+// FULL: all NLD loads of the item, no fused group in it.  Otherwise `nld` loads; FUSED: the item holds the fused group.
+template <bool FULL, int NLD = 8, bool FUSED = false>
+__device__ __forceinline__ void consume_item_scalar(const float* qp, uint32_t k0, uint32_t kf, uint32_t nld, const float4 (&v)[8], float& x)
+{
+#pragma unroll
+    for (int t = 0; t < NLD; t++)
+        if (FULL || (uint32_t)t < nld) {
+            const float4 q = *reinterpret_cast<const float4*>(qp + 32 * (t >> 1) + 4 * (t & 1));
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const float tt = f4_get(v[t], c) - f4_get(q, c);
+                if (!FUSED || k0 + 4 * t + c != kf) {
+                    const float sq = tt * tt;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) x = quad_from_previous_lane(x) + sq;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) x = __builtin_fmaf(tt, tt, quad_from_previous_lane(x));
+                }
+            }
+        }
+}
+
 // NL: 0, or the number of 16-byte loads per lane that make up a row when the kernel is built for that one row shape
 // (8: 128 dims, 6: 96 dims).
 template <bool SCALAR, int NBUF, bool IP = false, int SUB = -1, int NL = 0>
@@ -604,10 +611,11 @@ __device__ __forceinline__ void batch_distance(const DistCtx& c, const float* co
     typedef RowMap<SCALAR> RM;
     // (a kernel built for one row shape: one item of NL loads, known at compile time, so the loops below unroll into
     // straight-line code without a test per load)
-    static_assert(NL == 0 || (!SCALAR && NBUF == 2 && SUB < 0), "row-shape kernels read float rows in SSE order, one wavefront per query");
+    static_assert(NL == 0 || (NBUF == 2 && SUB < 0), "row-shape kernels run one wavefront per query");
     constexpr int NLD = NL ? NL : 8;
     const uint32_t ni = NL ? 1u : c.nitems, nf = NL ? 1u : c.nfull, tl = NL ? 0u : c.tail_loads;
-    const float* qs = c.qs + (SCALAR ? 0 : 8 * (lane & 3));
+    const float* qs = c.qs + 8 * (lane & 3);
+    const uint32_t kf = c.kf;
     float acc[RM::kSub];
 #pragma unroll
     for (int s = 0; s < RM::kSub; s++) acc[s] = 0.0f;
@@ -616,16 +624,20 @@ __device__ __forceinline__ void batch_distance(const DistCtx& c, const float* co
     // item i of the sequence: the sub-batches take turns, item i / kSub of sub-batch i % kSub
     const uint32_t total = (SUB < 0 ? RM::kSub : 1) * ni;
     auto issue = [&](float4 (&v)[8], uint32_t i) {
-        const uint32_t s = SCALAR ? 0u : (SUB < 0 ? (i & 1u) : (uint32_t)SUB), g = (SCALAR || SUB >= 0) ? i : (i >> 1);
+        const uint32_t s = SUB < 0 ? (i & 1u) : (uint32_t)SUB, g = SUB >= 0 ? i : (i >> 1);
         const float* p = (s ? row[RM::kSub - 1] : row[0]) + g * RM::kItemFloats;
         if (s ? act[RM::kSub - 1] : act[0]) { if (NL || g < nf) issue_item<SCALAR, true, NLD>(p, 0, v); else issue_item<SCALAR, false>(p, tl, v); }
     };
     auto consume = [&](const float4 (&v)[8], uint32_t i) {
-        const uint32_t s = SCALAR ? 0u : (SUB < 0 ? (i & 1u) : (uint32_t)SUB), g = (SCALAR || SUB >= 0) ? i : (i >> 1);
+        const uint32_t s = SUB < 0 ? (i & 1u) : (uint32_t)SUB, g = SUB >= 0 ? i : (i >> 1);
         const float* qp = qs + g * RM::kItemFloats;
         float a = s ? acc[RM::kSub - 1] : acc[0];
         if (s ? act[RM::kSub - 1] : act[0]) {
-            if (SCALAR) { if (g < nf) consume_item_scalar<true>(qp, 0, 0, v, a); else consume_item_scalar<false>(qp, g * RM::kItemFloats, c.d4, v, a); }
+            if (SCALAR) {
+                if (NL || g < nf) consume_item_scalar<true, NLD>(qp, 0, 0, 0, v, a);
+                else if (kf - 32u * g < 32u) consume_item_scalar<false, 8, true>(qp, 32u * g, kf, tl, v, a);      // the item with the fused group
+                else consume_item_scalar<false>(qp, 32u * g, kf, tl, v, a);
+            }
             else { if (NL || g < nf) consume_item_sse<true, IP, NLD, QRegs<NL>::K>(qp, 0, v, a, qr.q); else consume_item_sse<false, IP>(qp, tl, v, a, QRegs<0>().q); }
         }
         if (s) acc[RM::kSub - 1] = a; else acc[0] = a;
@@ -647,7 +659,11 @@ __device__ __forceinline__ void batch_distance(const DistCtx& c, const float* co
     }
 #pragma unroll
     for (int s = 0; s < RM::kSub; s++) {
-        if (SCALAR) { out[s] = acc[s]; continue; }
+        if (SCALAR) {
+            // the running sum ended its last round in lane 3 of the quad
+            out[s] = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(acc[s]), 0xFF, 0xF, 0xF, false));
+            continue;
+        }
         // sums 0..3 of a row sit in the 4 lanes of its quad: ((s0 + s1) + s2) + s3
         const int ai = (int)__float_as_uint(acc[s]);
         const float a0 = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, ai, 0x00, 0xF, 0xF, false));
@@ -716,7 +732,7 @@ __device__ __forceinline__ void rows_distance(const DeviceGraph& g, const DistCt
     } else {
         const float* row[RM::kSub];
 #pragma unroll
-        for (int s = 0; s < RM::kSub; s++) row[s] = g.vectors + (size_t)id[s] * g.row_stride + (SCALAR ? 0u : 8u * (lane & 3));
+        for (int s = 0; s < RM::kSub; s++) row[s] = g.vectors + (size_t)id[s] * g.row_stride + 8u * (lane & 3);
         batch_distance<SCALAR, NBUF, IP, SUB, NL>(c, row, act, out, lane, qr);
     }
 }
@@ -731,14 +747,12 @@ struct BatchLanes {
     // row of the list this lane holds in merged form, or >= deg when none
     static __device__ __forceinline__ uint32_t merged_row(int lane)
     {
-        if (SCALAR) return (uint32_t)lane;
         const uint32_t j = lane & 3, r = (uint32_t)lane >> 2;
         return j < 2 ? 2u * r + j : 0xFFFFu;
     }
     // value of sub-batch s for every lane of the quad, from the merged register
     static __device__ __forceinline__ uint32_t spread(uint32_t merged, int s)
     {
-        if (SCALAR) return merged;
         if (s == 0) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)merged, 0x00, 0xF, 0xF, false);   // quad_perm [0,0,0,0]
         return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)merged, 0x55, 0xF, 0xF, false);               // quad_perm [1,1,1,1]
     }
@@ -854,13 +868,12 @@ __device__ __forceinline__ uint32_t w_set_replace_max(uint32_t (&wd)[WR], uint32
 //       fused multiply-adds per lane, a distance batch gives every lane two rows, and the second wavefront takes the
 //       second of them (GIST-shaped 1M x 960, 1000 queries: 0.79 -> 1.06 M queries/s).
 // IP: inner-product metric (distance 1 - q.x) instead of squared L2; float rows, SSE order only.
-// (Except for the deep-prefetch form the kernels are held to 128 registers: four wavefronts per SIMD = 16 queries per CU.
-// The one-lane-per-row kernel for ef > 128 gets 168: it would spill 24 registers at 128, and at those ef the LDS a query
-// needs leaves a CU fewer than 12 queries anyway.)
-// NL: 0 = rows of any length; 8 / 6 = a kernel for rows of exactly 128 / 96 used dims (float rows, SSE order), whose
-//     distance batches are straight-line code.
+// (Except for the deep-prefetch form the kernels are held to 128 registers and pinned at four wavefronts per SIMD = 16
+// queries per CU.)
+// NL: 0 = rows of any length; 8 / 6 = a kernel for rows of exactly 128 / 96 used dims (float rows, SSE order), 7 = for the
+//     scalar order on rows of 97..112 dims without a fused tail (d = 100); their distance batches are straight-line code.
 template <bool SCALAR, int WR, int ROWS, bool BUCKET, int NBUF, bool IP, int NL>
-__global__ __launch_bounds__(NBUF == 2 ? 64 : 128) __attribute__((amdgpu_waves_per_eu(NBUF == 2 ? (SCALAR && WR == 4 ? 3 : 4) : 1, NBUF == 2 ? (SCALAR && WR == 4 ? 3 : 4) : 2))) void hnsw_search_kernel(SearchArgs a)
+__global__ __launch_bounds__(NBUF == 2 ? 64 : 128) __attribute__((amdgpu_waves_per_eu(NBUF == 2 ? 4 : 1, NBUF == 2 ? 4 : 2))) void hnsw_search_kernel(SearchArgs a)
 {
     typedef RowMap<SCALAR> RM;
     typedef BatchLanes<SCALAR> BL;
@@ -1003,7 +1016,7 @@ __global__ __launch_bounds__(NBUF == 2 ? 64 : 128) __attribute__((amdgpu_waves_p
 #pragma unroll
                     for (int s = 0; s < RM::kSub; s++) { rid[s] = BL::spread(my_order, s); act[s] = BL::spread((uint32_t)fresh, s) != 0; }
                     rows_distance<SCALAR, ROWS, NBUF, IP, -1, NL>(a.g, dc, rid, act, dj, lane, qr);
-                    dm = (!SCALAR && (lane & 3) == 1) ? dj[RM::kSub - 1] : dj[0];
+                    dm = (lane & 3) == 1 ? dj[RM::kSub - 1] : dj[0];
                 }
                 const bool mine = fresh && dm == dm;
                 const uint32_t key = mine ? __float_as_uint(dm) : 0x7F800000u;     // non-negative floats order as their bit patterns
@@ -1102,7 +1115,7 @@ __global__ __launch_bounds__(NBUF == 2 ? 64 : 128) __attribute__((amdgpu_waves_p
 #pragma unroll
                         for (int s = 0; s < RM::kSub; s++) { rid[s] = BL::spread(my, s); act[s] = BL::spread((uint32_t)fresh, s) != 0; }
                         rows_distance<SCALAR, ROWS, NBUF, IP, -1, NL>(a.g, dc, rid, act, dj, lane, qr);
-                        dm = (!SCALAR && (lane & 3) == 1) ? dj[RM::kSub - 1] : dj[0];
+                        dm = (lane & 3) == 1 ? dj[RM::kSub - 1] : dj[0];
                     }
                     DIAG_STAMP(t3);
                     DIAG_ADD(cy_dist, t2, t3);
@@ -1402,7 +1415,12 @@ __global__ void store_rows_q8_kernel(const float* __restrict__ src, uint8_t* __r
 
 // Rows of exactly 128 or 96 used dims (the SSE loop uses the first 16 * floor(d / 16)) have kernels of their own whose
 // distance batches are straight-line code; 0 = the kernel for any row length.
-static int row_shape_loads(uint32_t d) { const uint32_t d_eff = d & ~15u; return d_eff == 128u ? 8 : (d_eff == 96u ? 6 : 0); }
+static int row_shape_loads(uint32_t d, bool scalar = false)
+{
+    if (scalar) return (d > 96u && d <= 112u && (d & 3u) == 0u) ? 7 : 0;      // scalar order: all dims, 7 loads (d = 100), no fused tail
+    const uint32_t d_eff = d & ~15u;
+    return d_eff == 128u ? 8 : (d_eff == 96u ? 6 : 0);
+}
 
 size_t search_lds_bytes(const SearchArgs& a, bool w_in_lds)
 {
@@ -1638,6 +1656,7 @@ template <bool BUCKET>
 static SearchKernel pick_rows(bool scalar, int wr, int rows, bool ip, int nl)
 {
     if (ip) return pick_wr<false, 0, BUCKET, 2, true>(wr);
+    if (scalar && nl == 7) return pick_wr<true, 0, BUCKET, 2, false, 7>(wr);
     if (scalar) return pick_wr<true, 0, BUCKET, 2>(wr);
     if (rows == 1) return pick_wr<false, 1, BUCKET, 2>(wr);
     if (rows == 2) return pick_wr<false, 2, BUCKET, 2>(wr);
@@ -1650,7 +1669,7 @@ static SearchKernel pick_rows(bool scalar, int wr, int rows, bool ip, int nl)
 static SearchKernel pick_kernel(bool scalar, int wr, int rows, bool bucket, bool ip, uint32_t d, bool deep = false)
 {
     if (deep && !scalar && rows == 0 && !bucket && !ip) return pick_wr<false, 0, false, 6>(wr);
-    const int nl = getenv("HNSW_AMD_GENERIC_ROWS") ? 0 : row_shape_loads(d);       // (diagnostics: the kernel for any row length)
+    const int nl = getenv("HNSW_AMD_GENERIC_ROWS") ? 0 : row_shape_loads(d, scalar);       // (diagnostics: the kernel for any row length)
     return bucket ? pick_rows<true>(scalar, wr, rows, ip, nl) : pick_rows<false>(scalar, wr, rows, ip, nl);
 }
 

@@ -49,6 +49,37 @@ def test_config_shape_matches_oracle(kind, n, nq, efs):
     assert recall_at_k(ids, gt, 10) > 0.9
 
 
+@pytest.mark.parametrize("d", [30, 50, 100, 128, 131, 200])
+def test_scalar_order_at_every_row_shape(d, monkeypatch):
+    """The reference's plain distance loop (-DNO_MANUAL_VECTORIZATION, src/hnsw.h:387-400): one running sum over all d
+    dims, the last d % 4 fused.  Shapes: shorter than one 128-dim item, the fused group inside the only item (50), the
+    shape with kernels of its own (100; also run with the kernel for any row length), exactly one item (128), the fused
+    group in a second item (131), two items (200).  Against the CPU restatement: distances bit for bit, counters equal."""
+    rng = np.random.default_rng(d)
+    n, nq = 4000, 200
+    base = rng.standard_normal((n, d)).astype(np.float32)
+    base /= np.linalg.norm(base, axis=1, keepdims=True)
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    h = HNSW(16, 16, 100)
+    h.init(d, n)
+    h.insert_batch(base, threads=16)
+    idx = oracle.OracleIndex(h.export_flat(), base)
+    flags = capi.DIST_SCALAR | capi.KEYS_INT32
+    for ef in (10, 70, 150):
+        oi, od, oc, ost = idx.search(q, ef, dist_mode=1, stats=True, threads=8)
+        for generic in ((False, True) if d == 100 else (False,)):
+            if generic:
+                monkeypatch.setenv("HNSW_AMD_GENERIC_ROWS", "1")
+            else:
+                monkeypatch.delenv("HNSW_AMD_GENERIC_ROWS", raising=False)
+            ids, dist, cnt, st = h.search_batch(q, ef, flags=flags, stats=True)
+            assert np.array_equal(cnt, oc)
+            assert_same_results(ids, dist, oi, od, what=f"scalar order d={d} ef={ef} generic={generic}")
+            for field in st.dtype.names:
+                assert np.array_equal(st[field], ost[field]), f"d={d} ef={ef}: counter {field}"
+
+
 def test_unit_norm_float_keys_do_less_work_but_differ():
     """On unit-norm data the reference's int32 candidate keys are all 0..3, so its search never
     stops early (src/hnsw.cpp:748,767); float keys are the textbook behaviour."""
@@ -67,11 +98,11 @@ def test_unit_norm_float_keys_do_less_work_but_differ():
     (24, "sift", capi.DIST_SSE),                      # layer-0 lists of 48: a full batch of 32 rows and half a second one
     (32, "sift", capi.DIST_SSE),                      # layer-0 lists of 64: two full batches
     (32, "deep", capi.DIST_SSE | capi.W_STD_HEAP),
-    (32, "glove", capi.DIST_SCALAR),                  # one lane per row: 64 rows in one batch
+    (32, "glove", capi.DIST_SCALAR),                  # scalar order: the running sum rotates through the quad
     (12, "glove", capi.DIST_SCALAR | capi.KEYS_FLOAT),
 ])
 def test_other_list_lengths_match_oracle(M, kind, flags):
-    """The kernel handles a neighbour list in batches of 32 rows (64 in scalar mode); lists of other
+    """The kernel handles a neighbour list in batches of 32 rows; lists of other
     lengths than the benchmark's 2*16 exercise the partial and the repeated batch."""
     n, nq = 12000, 200
     base = datagen.make(kind, n, seed=5)
