@@ -503,16 +503,19 @@ __device__ __forceinline__ void issue_item(const float* p, uint32_t nld, float4 
 // A kernel built for one row shape keeps the lane's pieces of the query in registers for the whole search (all six
 // of a 96-dim row; the first four of a 128-dim row, whose kernels have less room), so that a distance batch does not
 // wait for them to come out of LDS piece by piece.
-template <int NL>
+// (Byte rows of 128 dims: all eight pieces, in the byte rows' own order of the query copy; those kernels have the room.)
+template <int NL, int ROWS = 0>
 struct QRegs {
-    static constexpr int K = NL == 6 ? 6 : (NL == 8 ? 4 : 0);       // (the scalar-order kernels, NL = 7, read the query from LDS)
+    // (the scalar-order kernels, NL = 7, read the query from LDS)
+    static constexpr int K = ROWS != 0 ? (NL == 8 ? 8 : 0) : (NL == 6 ? 6 : (NL == 8 ? 4 : 0));
     float4 q[K ? K : 1];
 };
-template <int NL>
-__device__ __forceinline__ void qregs_load(QRegs<NL>& qr, const float* qs, int lane)
+template <int NL, int ROWS>
+__device__ __forceinline__ void qregs_load(QRegs<NL, ROWS>& qr, const float* qs, int lane)
 {
 #pragma unroll
-    for (int t = 0; t < QRegs<NL>::K; t++) qr.q[t] = *reinterpret_cast<const float4*>(qs + 8 * (lane & 3) + 32 * (t >> 1) + 4 * (t & 1));
+    for (int t = 0; t < QRegs<NL, ROWS>::K; t++)
+        qr.q[t] = *reinterpret_cast<const float4*>(ROWS != 0 ? qs + 32 * (lane & 3) + 4 * t : qs + 8 * (lane & 3) + 32 * (t >> 1) + 4 * (t & 1));
 }
 
 // SSE order, lane j of the row's quad: p / qp point at this lane's 8 floats of the item's first line.
@@ -548,13 +551,13 @@ __device__ __forceinline__ void issue_item_u8(const uint8_t* p, uint4 (&v)[2])
 
 __device__ __forceinline__ uint32_t u4_get(const uint4& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
 
-template <bool FULL>
-__device__ __forceinline__ void consume_item_u8(const float* qp, uint32_t nwords, const uint4 (&v)[2], float& a)
+template <bool FULL, int QK = 0>
+__device__ __forceinline__ void consume_item_u8(const float* qp, uint32_t nwords, const uint4 (&v)[2], float& a, const float4 (&qk)[QK ? QK : 1])
 {
 #pragma unroll
     for (int w = 0; w < 8; w++)
         if (FULL || (uint32_t)w < nwords) {
-            const float4 q = *reinterpret_cast<const float4*>(qp + 4 * w);
+            const float4 q = w < QK ? qk[w] : *reinterpret_cast<const float4*>(qp + 4 * w);
             const uint32_t word = u4_get(v[w >> 2], w & 3);
             const float dx = (float)(word & 0xFFu) - q.x, dy = (float)((word >> 8) & 0xFFu) - q.y;
             const float dz = (float)((word >> 16) & 0xFFu) - q.z, dw = (float)(word >> 24) - q.w;
@@ -678,10 +681,13 @@ __device__ __forceinline__ void batch_distance(const DistCtx& c, const float* co
 }
 
 // The same for byte rows (SSE order only): row[s] points at this lane's 32 bytes of the row's first block.
+// NL = 8: a kernel built for rows of 128 dims (one block, known at compile time: the loop below unrolls into straight-line code).
+template <int NL = 0>
 __device__ __forceinline__ void batch_distance_u8(const DistCtx& c, const uint8_t* const (&row)[2], const bool (&act)[2],
-                                                  float (&out)[2], int lane)
+                                                  float (&out)[2], int lane, const QRegs<NL, 1>& qr = QRegs<NL, 1>())
 {
-    const uint32_t ni = c.nitems, nf = c.nfull, tl = c.tail_loads;
+    static_assert(NL == 0 || NL == 8, "byte rows: the kernel for any row length, or the one for 128 dims");
+    const uint32_t ni = NL ? 1u : c.nitems, nf = NL ? 1u : c.nfull, tl = NL ? 0u : c.tail_loads;
     const float* qs = c.qs + 32 * (lane & 3);
     float acc[2] = {0.0f, 0.0f};
     uint4 A[2], B[2];
@@ -693,7 +699,7 @@ __device__ __forceinline__ void batch_distance_u8(const DistCtx& c, const uint8_
     auto consume = [&](const uint4 (&v)[2], uint32_t i) {
         const uint32_t s = i >= ni ? 1u : 0u, g = i - s * ni;
         float a = s ? acc[1] : acc[0];
-        if (s ? act[1] : act[0]) { if (g < nf) consume_item_u8<true>(qs + g * 128u, 0, v, a); else consume_item_u8<false>(qs + g * 128u, tl, v, a); }
+        if (s ? act[1] : act[0]) { if (NL || g < nf) consume_item_u8<true, QRegs<NL, 1>::K>(qs + g * 128u, 0, v, a, qr.q); else consume_item_u8<false>(qs + g * 128u, tl, v, a, QRegs<0, 1>().q); }
         if (s) acc[1] = a; else acc[0] = a;
     };
     issue(A, 0);
@@ -719,7 +725,7 @@ __device__ __forceinline__ void batch_distance_u8(const DistCtx& c, const uint8_
 template <bool SCALAR, int ROWS, int NBUF = 2, bool IP = false, int SUB = -1, int NL = 0>
 __device__ __forceinline__ void rows_distance(const DeviceGraph& g, const DistCtx& c, const uint32_t (&id)[RowMap<SCALAR>::kSub],
                                               const bool (&act)[RowMap<SCALAR>::kSub], float (&out)[RowMap<SCALAR>::kSub], int lane,
-                                              const QRegs<NL>& qr = QRegs<NL>())
+                                              const QRegs<NL, (ROWS != 0 ? 1 : 0)>& qr = QRegs<NL, (ROWS != 0 ? 1 : 0)>())
 {
     typedef RowMap<SCALAR> RM;
     if constexpr (ROWS != 0) {
@@ -728,7 +734,7 @@ __device__ __forceinline__ void rows_distance(const DeviceGraph& g, const DistCt
         const uint8_t* row[2];
 #pragma unroll
         for (int s = 0; s < 2; s++) row[s] = table + (size_t)id[s] * g.row_stride_u8 + 32u * (lane & 3);
-        batch_distance_u8(c, row, act, out, lane);
+        batch_distance_u8<NL>(c, row, act, out, lane, qr);
     } else {
         const float* row[RM::kSub];
 #pragma unroll
@@ -956,7 +962,7 @@ __global__ __launch_bounds__(NBUF == 2 ? 64 : 128) __attribute__((amdgpu_waves_p
         for (uint32_t i = lane; i < hash_words; i += 64) hash[i] = kEmpty;
     }
     LDS_SYNC();
-    QRegs<NL> qr;
+    QRegs<NL, (ROWS != 0 ? 1 : 0)> qr;
     qregs_load(qr, qs, lane);
 
     hnsw_amd_query_stats st = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1658,6 +1664,8 @@ static SearchKernel pick_rows(bool scalar, int wr, int rows, bool ip, int nl)
     if (ip) return pick_wr<false, 0, BUCKET, 2, true>(wr);
     if (scalar && nl == 7) return pick_wr<true, 0, BUCKET, 2, false, 7>(wr);
     if (scalar) return pick_wr<true, 0, BUCKET, 2>(wr);
+    if (rows == 1 && nl == 8) return pick_wr<false, 1, BUCKET, 2, false, 8>(wr);
+    if (rows == 2 && nl == 8) return pick_wr<false, 2, BUCKET, 2, false, 8>(wr);
     if (rows == 1) return pick_wr<false, 1, BUCKET, 2>(wr);
     if (rows == 2) return pick_wr<false, 2, BUCKET, 2>(wr);
     if (nl == 8) return pick_wr<false, 0, BUCKET, 2, false, 8>(wr);
