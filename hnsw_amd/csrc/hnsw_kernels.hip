@@ -612,11 +612,14 @@ __device__ __forceinline__ void batch_distance(const DistCtx& c, const float* co
                                                const QRegs<NL>& qr = QRegs<NL>())
 {
     typedef RowMap<SCALAR> RM;
-    // (a kernel built for one row shape: one item of NL loads, known at compile time, so the loops below unroll into
-    // straight-line code without a test per load)
-    static_assert(NL == 0 || (NBUF == 2 && SUB < 0), "row-shape kernels run one wavefront per query");
-    constexpr int NLD = NL ? NL : 8;
-    const uint32_t ni = NL ? 1u : c.nitems, nf = NL ? 1u : c.nfull, tl = NL ? 0u : c.tail_loads;
+    // (a kernel built for one row shape knows the items at compile time — NL < 100: one item of NL loads; NL = 100 F + T: F
+    // whole items and a last one of T loads — so the loops below unroll into straight-line code without a test per load)
+    static_assert(NL == 0 || NL >= 100 || (NBUF == 2 && SUB < 0), "single-item row-shape kernels run one wavefront per query");
+    constexpr int kNF = NL >= 100 ? NL / 100 : 0;          // whole items before the last one
+    constexpr int kTL = NL >= 100 ? NL % 100 : NL;         // loads of the last (or only) item
+    constexpr int NLD = kTL ? kTL : 8;
+    constexpr int kUnroll = NL >= 100 ? 32 : 1;            // (a multi-item shape: the item loop unrolls completely)
+    const uint32_t ni = NL ? (uint32_t)(kNF + (kTL ? 1 : 0)) : c.nitems, nf = NL ? (uint32_t)kNF : c.nfull, tl = NL ? 0u : c.tail_loads;
     const float* qs = c.qs + 8 * (lane & 3);
     const uint32_t kf = c.kf;
     float acc[RM::kSub];
@@ -629,7 +632,7 @@ __device__ __forceinline__ void batch_distance(const DistCtx& c, const float* co
     auto issue = [&](float4 (&v)[8], uint32_t i) {
         const uint32_t s = SUB < 0 ? (i & 1u) : (uint32_t)SUB, g = SUB >= 0 ? i : (i >> 1);
         const float* p = (s ? row[RM::kSub - 1] : row[0]) + g * RM::kItemFloats;
-        if (s ? act[RM::kSub - 1] : act[0]) { if (NL || g < nf) issue_item<SCALAR, true, NLD>(p, 0, v); else issue_item<SCALAR, false>(p, tl, v); }
+        if (s ? act[RM::kSub - 1] : act[0]) { if (g < nf) issue_item<SCALAR, true>(p, 0, v); else if (NL) issue_item<SCALAR, true, NLD>(p, 0, v); else issue_item<SCALAR, false>(p, tl, v); }
     };
     auto consume = [&](const float4 (&v)[8], uint32_t i) {
         const uint32_t s = SUB < 0 ? (i & 1u) : (uint32_t)SUB, g = SUB >= 0 ? i : (i >> 1);
@@ -637,11 +640,16 @@ __device__ __forceinline__ void batch_distance(const DistCtx& c, const float* co
         float a = s ? acc[RM::kSub - 1] : acc[0];
         if (s ? act[RM::kSub - 1] : act[0]) {
             if (SCALAR) {
-                if (NL || g < nf) consume_item_scalar<true, NLD>(qp, 0, 0, 0, v, a);
+                if (g < nf) consume_item_scalar<true>(qp, 0, 0, 0, v, a);
+                else if (NL) consume_item_scalar<true, NLD>(qp, 0, 0, 0, v, a);
                 else if (kf - 32u * g < 32u) consume_item_scalar<false, 8, true>(qp, 32u * g, kf, tl, v, a);      // the item with the fused group
                 else consume_item_scalar<false>(qp, 32u * g, kf, tl, v, a);
             }
-            else { if (NL || g < nf) consume_item_sse<true, IP, NLD, QRegs<NL>::K>(qp, 0, v, a, qr.q); else consume_item_sse<false, IP>(qp, tl, v, a, QRegs<0>().q); }
+            else {
+                if (g < nf) consume_item_sse<true, IP>(qp, 0, v, a, QRegs<0>().q);
+                else if (NL) consume_item_sse<true, IP, NLD, QRegs<NL>::K>(qp, 0, v, a, qr.q);
+                else consume_item_sse<false, IP>(qp, tl, v, a, QRegs<0>().q);
+            }
         }
         if (s) acc[RM::kSub - 1] = a; else acc[0] = a;
     };
@@ -651,6 +659,7 @@ __device__ __forceinline__ void batch_distance(const DistCtx& c, const float* co
 #pragma unroll
     for (int b = 0; b < NBUF; b++)
         if ((uint32_t)b < total) issue(buf[b], b);
+#pragma unroll kUnroll
     for (uint32_t i = 0; i < total; i += NBUF) {
 #pragma unroll
         for (int b = 0; b < NBUF; b++)
@@ -876,8 +885,9 @@ __device__ __forceinline__ uint32_t w_set_replace_max(uint32_t (&wd)[WR], uint32
 // IP: inner-product metric (distance 1 - q.x) instead of squared L2; float rows, SSE order only.
 // (Except for the deep-prefetch form the kernels are held to 128 registers and pinned at four wavefronts per SIMD = 16
 // queries per CU.)
-// NL: 0 = rows of any length; 8 / 6 = a kernel for rows of exactly 128 / 96 used dims (float rows, SSE order), 7 = for the
-//     scalar order on rows of 97..112 dims without a fused tail (d = 100); their distance batches are straight-line code.
+// NL: 0 = rows of any length; 8 / 6 = a kernel for rows of exactly 128 / 96 used dims (float rows, SSE order; 8 also for byte
+//     rows), 7 = for the scalar order on rows of 97..112 dims without a fused tail (d = 100), 704 = the deep form for rows of
+//     960 used dims (7 whole items + 4 loads); their distance batches are straight-line code.
 template <bool SCALAR, int WR, int ROWS, bool BUCKET, int NBUF, bool IP, int NL>
 __global__ __launch_bounds__(NBUF == 2 ? 64 : 128) __attribute__((amdgpu_waves_per_eu(NBUF == 2 ? 4 : 1, NBUF == 2 ? 4 : 2))) void hnsw_search_kernel(SearchArgs a)
 {
@@ -903,7 +913,7 @@ __global__ __launch_bounds__(NBUF == 2 ? 64 : 128) __attribute__((amdgpu_waves_p
 #pragma unroll
             for (int s = 0; s < RM::kSub; s++) { rid[s] = BL::spread(my, s); act[s] = BL::spread(fresh, s) != 0; }
             const DistCtx dc = make_dist_ctx<SCALAR>(reinterpret_cast<float*>(smem), a.g.d);
-            rows_distance<SCALAR, ROWS, NBUF, IP, 1>(a.g, dc, rid, act, dj, lane);
+            rows_distance<SCALAR, ROWS, NBUF, IP, 1, (kHelper ? NL : 0)>(a.g, dc, rid, act, dj, lane);
             if ((lane & 3) == 1) mail[128 + lane] = __float_as_uint(dj[RM::kSub - 1]);
             __syncthreads();                                 // the distances are in the mailbox
         }
@@ -917,7 +927,7 @@ __global__ __launch_bounds__(NBUF == 2 ? 64 : 128) __attribute__((amdgpu_waves_p
         uint32_t rid[RM::kSub]; bool act[RM::kSub]; float dj[RM::kSub];
 #pragma unroll
         for (int s = 0; s < RM::kSub; s++) { rid[s] = BL::spread(my, s); act[s] = BL::spread((uint32_t)fresh, s) != 0; }
-        rows_distance<SCALAR, ROWS, NBUF, IP, 0>(a.g, dc, rid, act, dj, lane);
+        rows_distance<SCALAR, ROWS, NBUF, IP, 0, (kHelper ? NL : 0)>(a.g, dc, rid, act, dj, lane);
         __syncthreads();
         return (lane & 3) == 1 ? __uint_as_float(mail[128 + lane]) : dj[0];
     };
@@ -1676,8 +1686,13 @@ static SearchKernel pick_rows(bool scalar, int wr, int rows, bool ip, int nl)
 // deep: the float-row, probing-form kernel with six row pieces in flight and two wavefronts per query (see hnsw_search_kernel)
 static SearchKernel pick_kernel(bool scalar, int wr, int rows, bool bucket, bool ip, uint32_t d, bool deep = false)
 {
-    if (deep && !scalar && rows == 0 && !bucket && !ip) return pick_wr<false, 0, false, 6>(wr);
-    const int nl = getenv("HNSW_AMD_GENERIC_ROWS") ? 0 : row_shape_loads(d, scalar);       // (diagnostics: the kernel for any row length)
+    const bool generic = getenv("HNSW_AMD_GENERIC_ROWS") != nullptr;                      // (diagnostics: the kernel for any row length)
+    if (deep && !scalar && rows == 0 && !bucket && !ip) {
+        // (960 used dims = seven whole 128-dim items and one of four loads: the shape of the configuration this form exists for)
+        if (!generic && (d & ~15u) == 960u) return pick_wr<false, 0, false, 6, false, 704>(wr);
+        return pick_wr<false, 0, false, 6>(wr);
+    }
+    const int nl = generic ? 0 : row_shape_loads(d, scalar);
     return bucket ? pick_rows<true>(scalar, wr, rows, ip, nl) : pick_rows<false>(scalar, wr, rows, ip, nl);
 }
 
