@@ -604,8 +604,9 @@ __device__ __forceinline__ void consume_item_scalar(const float* qp, uint32_t k0
         }
 }
 
-// NL: 0, or the number of 16-byte loads per lane that make up a row when the kernel is built for that one row shape
-// (8: 128 dims, 6: 96 dims).
+// NL: 0, or the row shape the kernel is built for: the number of 16-byte loads per lane that make up a row of at most
+// 128 dims (8: 128 dims, 6: 96 dims, 7: 100 dims in scalar order), or 100 F + T for a row of F whole 128-dim items and
+// a last one of T loads (704: 960 dims).
 template <bool SCALAR, int NBUF, bool IP = false, int SUB = -1, int NL = 0>
 __device__ __forceinline__ void batch_distance(const DistCtx& c, const float* const (&row)[RowMap<SCALAR>::kSub],
                                                const bool (&act)[RowMap<SCALAR>::kSub], float (&out)[RowMap<SCALAR>::kSub], int lane,
@@ -625,7 +626,6 @@ __device__ __forceinline__ void batch_distance(const DistCtx& c, const float* co
     float acc[RM::kSub];
 #pragma unroll
     for (int s = 0; s < RM::kSub; s++) acc[s] = 0.0f;
-    {
     float4 buf[NBUF][8];
     // item i of the sequence: the sub-batches take turns, item i / kSub of sub-batch i % kSub
     const uint32_t total = (SUB < 0 ? RM::kSub : 1) * ni;
@@ -667,7 +667,6 @@ __device__ __forceinline__ void batch_distance(const DistCtx& c, const float* co
                 consume(buf[b], i + b);
                 if (i + b + NBUF < total) issue(buf[b], i + b + NBUF);
             }
-    }
     }
 #pragma unroll
     for (int s = 0; s < RM::kSub; s++) {
