@@ -1000,6 +1000,12 @@ __global__ __launch_bounds__(NBUF == 2 ? 64 : 128) __attribute__((amdgpu_waves_p
 
     // ---- greedy descent through layers L..1; visited shared by all of them
     //      (src/hnsw.cpp:403-412, 676-717) ----
+    // Lists of at most 16 rows (M = 16: every upper-layer list) go one row per quad into sub-batch 0 alone: one chain of
+    // loads and multiply-adds per lane instead of two half-empty ones.  Lane order is still list order.  (Not in the
+    // two-wavefront form, whose second wavefront lives on sub-batch 1.)
+    const bool narrow_up = !kHelper && a.g.degu <= (uint32_t)RM::kRowsPerSub;
+    const uint32_t mrow_up = narrow_up ? ((lane & 3) == 0 ? (uint32_t)lane >> 2 : 0xFFFFu) : mrow;
+    const uint32_t step_up = narrow_up ? (uint32_t)RM::kRowsPerSub : (uint32_t)RM::kRowsPerBatch;
     for (int l = L; l > 0 && !fail; l--) {
         const uint32_t base = a.g.up_off[l];
         bool change = true;
@@ -1010,9 +1016,9 @@ __global__ __launch_bounds__(NBUF == 2 ? 64 : 128) __attribute__((amdgpu_waves_p
             // The sweep covers the whole list of the node current at its start; the running best moves
             // only on a strict improvement, i.e. to the first minimum of the list.
             const size_t rowi = (size_t)(base + cur_slot) * a.g.degu;
-            for (uint32_t b0 = 0; b0 < a.g.degu; b0 += RM::kRowsPerBatch) {
+            for (uint32_t b0 = 0; b0 < a.g.degu; b0 += step_up) {
                 uint32_t my_order = kEmpty, my_slot = kEmpty;           // merged form
-                if (b0 + mrow < a.g.degu) { my_order = a.g.up_adj_order[rowi + b0 + mrow]; my_slot = a.g.up_adj_slot[rowi + b0 + mrow]; }
+                if (b0 + mrow_up < a.g.degu) { my_order = a.g.up_adj_order[rowi + b0 + mrow_up]; my_slot = a.g.up_adj_slot[rowi + b0 + mrow_up]; }
                 const bool live = my_order != kEmpty;
                 used_ovf = false;
                 const bool fresh = live && visited_insert<BUCKET>(vs, nullptr, my_order, vis_ovf, used_ovf);
