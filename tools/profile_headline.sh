@@ -1,12 +1,12 @@
 set -e
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-mkdir -p $R/gpurun_out/prof_v5
+mkdir -p $R/gpurun_out/prof_v6
 cd /tmp
 export HNSW_AMD_BENCH_CACHE=/tmp/bcache
 mkdir -p /tmp/bcache
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_v5 -- python3 $R/bench.py --steps 10 --cpu-baseline none > $R/gpurun_out/prof_v5/bench_under_rocprof.json 2> $R/gpurun_out/prof_v5/err.log
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_v6 -- python3 $R/bench.py --steps 10 --cpu-baseline none > $R/gpurun_out/prof_v6/bench_under_rocprof.json 2> $R/gpurun_out/prof_v6/err.log
 cd $R
-timeout -k 10 900 bash tools/pmc_passes.sh pmc_v7
-python3 tools/pmc_summary.py gpurun_out/pmc_v7 > gpurun_out/pmc_v7/summary.json
-timeout -k 10 400 python -u bench.py 2>/dev/null | tee gpurun_out/bench_final_v5.json
+timeout -k 10 900 bash tools/pmc_passes.sh pmc_v8
+python3 tools/pmc_summary.py gpurun_out/pmc_v8 > gpurun_out/pmc_v8/summary.json
+timeout -k 10 400 python -u bench.py 2>/dev/null | tee gpurun_out/bench_final_v6.json

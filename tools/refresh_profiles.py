@@ -5,17 +5,17 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "v4"
 rnd = sys.argv[2] if len(sys.argv) > 2 else "r2"      # round prefix of the file names
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 g = lambda *p: os.path.join(R, *p)
-shutil.copy(g("gpurun_out", "pmc_v7", "summary.json"), g("profiles", f"{rnd}_pmc_search_kernel_{tag}.json"))
-shutil.copy(g("gpurun_out", "pmc_v7", "summary.json"), g("profiles", "pmc_search_kernel_latest.json"))
-shutil.copy(g("gpurun_out", "bench_final_v5.json"), g("profiles", f"{rnd}_bench_1m_{tag}.json"))
-shutil.copy(g("gpurun_out", "prof_v5", "bench_under_rocprof.json"), g("profiles", f"{rnd}_bench_1m_{tag}_under_rocprof.json"))
-stats = max(glob.glob(g("gpurun_out", "prof_v5", "vm", "*_kernel_stats.csv")), key=os.path.getmtime)
+shutil.copy(g("gpurun_out", "pmc_v8", "summary.json"), g("profiles", f"{rnd}_pmc_search_kernel_{tag}.json"))
+shutil.copy(g("gpurun_out", "pmc_v8", "summary.json"), g("profiles", "pmc_search_kernel_latest.json"))
+shutil.copy(g("gpurun_out", "bench_final_v6.json"), g("profiles", f"{rnd}_bench_1m_{tag}.json"))
+shutil.copy(g("gpurun_out", "prof_v6", "bench_under_rocprof.json"), g("profiles", f"{rnd}_bench_1m_{tag}_under_rocprof.json"))
+stats = max(glob.glob(g("gpurun_out", "prof_v6", "vm", "*_kernel_stats.csv")), key=os.path.getmtime)
 rows = list(csv.DictReader(open(stats)))
 with open(g("profiles", f"{rnd}_bench_1m_{tag}_kernel_stats.csv"), "w", newline="") as o:
     w = csv.DictWriter(o, fieldnames=rows[0].keys()); w.writeheader()
     for r in rows:
         r["Name"] = r["Name"][:120]; w.writerow(r)
-trace = max(glob.glob(g("gpurun_out", "prof_v5", "vm", "*_kernel_trace.csv")), key=os.path.getmtime)
+trace = max(glob.glob(g("gpurun_out", "prof_v6", "vm", "*_kernel_trace.csv")), key=os.path.getmtime)
 tr = [r for r in csv.DictReader(open(trace)) if "hnsw_search_kernel" in r["Kernel_Name"]]
 keys = [k for k in ["Dispatch_Id", "Start_Timestamp", "End_Timestamp", "LDS_Block_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count",
                     "Workgroup_Size", "Grid_Size"] if k in tr[0]]
