@@ -1676,6 +1676,8 @@ static SearchKernel pick_wr(int wr)
 template <bool BUCKET>
 static SearchKernel pick_rows(bool scalar, int wr, int rows, bool ip, int nl)
 {
+    if (ip && nl == 8) return pick_wr<false, 0, BUCKET, 2, true, 8>(wr);
+    if (ip && nl == 6) return pick_wr<false, 0, BUCKET, 2, true, 6>(wr);
     if (ip) return pick_wr<false, 0, BUCKET, 2, true>(wr);
     if (scalar && nl == 7) return pick_wr<true, 0, BUCKET, 2, false, 7>(wr);
     if (scalar) return pick_wr<true, 0, BUCKET, 2>(wr);

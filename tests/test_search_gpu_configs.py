@@ -156,6 +156,31 @@ def test_odd_dimensions_match_oracle(d):
                 assert np.array_equal(st[field], ost[field]), f"d={d} flags={flags} ef={ef}: counter {field}"
 
 
+@pytest.mark.parametrize("d", [72, 128])
+def test_inner_product_metric_at_other_row_shapes(d):
+    """The inner-product metric on rows of 128 dims (a kernel built for that shape) and of 64 used dims (the kernel for any
+    row length); the 96-dim shape is the DEEP-shaped case below.  PARITY UNPINNED, as there."""
+    from oracle import oracle
+    from tests.helpers import assert_same_results
+    rng = np.random.default_rng(100 + d)
+    base = rng.standard_normal((20000, d)).astype(np.float32)
+    base /= np.linalg.norm(base, axis=1, keepdims=True)
+    q = rng.standard_normal((200, d)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    h = HNSW(16, 16, 100)
+    h.init(d, len(base))
+    h.set_build_float_keys(True)
+    h.insert_batch(base, threads=16)
+    idx = oracle.OracleIndex(h.export_flat(), base)
+    for ef in (16, 100):
+        ids, dist, cnt, st = h.search_batch(q, ef, flags=capi.DIST_SSE | capi.METRIC_IP | capi.KEYS_FLOAT, stats=True)
+        oi, od, oc, ost = idx.search(q, ef, dist_mode=oracle.DIST_IP, key_mode=oracle.KEYS_FLOAT, stats=True)
+        assert np.array_equal(cnt, oc)
+        assert_same_results(ids, dist, oi, od, what=f"inner product, d={d}, ef={ef}")
+        for f in st.dtype.names:
+            assert np.array_equal(st[f], ost[f]), f"d={d} ef={ef}: counter {f}"
+
+
 @pytest.mark.parametrize("keys", ["float", "int32"])
 def test_inner_product_metric_against_the_cpu_restatement(keys):
     """HNSW_AMD_METRIC_IP: distance max(0, 1 - q.x) in the SSE loop's summation order.  PARITY UNPINNED: the reference has
