@@ -1128,13 +1128,26 @@ __global__ __launch_bounds__(NBUF == 2 ? 64 : 128) __attribute__((amdgpu_waves_p
                 DIAG_STAMP(t2);
                 DIAG_ADD(cy_adj, t1b, t2);
                 if (m != 0) {
+                    // At most 16 fresh rows (the rule at large ef): they are moved, in list order, one per quad into
+                    // sub-batch 0 (lane 4r takes the r-th fresh row through one cross-lane push), so that the batch is one
+                    // chain of loads and multiply-adds per lane instead of two sparsely filled ones.  What follows takes
+                    // the batch in either form: lane order is list order in both.
+                    uint32_t my_b = my;
+                    bool fresh_b = fresh;
+                    if (!kHelper && WR != 1 && m <= (uint32_t)RM::kRowsPerSub) {      // (ef <= 64: most batches hold more, measured no gain)
+                        const unsigned long long fm = __ballot(fresh);
+                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
+                        const uint32_t to = fresh ? 4u * rank : 63u;          // (lane 63 holds no row in this form)
+                        my_b = (uint32_t)__builtin_amdgcn_ds_permute((int)(to << 2), (int)my);
+                        fresh_b = (lane & 3) == 0 && ((uint32_t)lane >> 2) < m;
+                    }
                     float dm;                                                                  // merged form
                     if constexpr (kHelper) {
                         dm = batch_with_helper(my, fresh, dc);
                     } else {
                         uint32_t rid[RM::kSub]; bool act[RM::kSub]; float dj[RM::kSub];
 #pragma unroll
-                        for (int s = 0; s < RM::kSub; s++) { rid[s] = BL::spread(my, s); act[s] = BL::spread((uint32_t)fresh, s) != 0; }
+                        for (int s = 0; s < RM::kSub; s++) { rid[s] = BL::spread(my_b, s); act[s] = BL::spread((uint32_t)fresh_b, s) != 0; }
                         rows_distance<SCALAR, ROWS, NBUF, IP, -1, NL>(a.g, dc, rid, act, dj, lane, qr);
                         dm = (lane & 3) == 1 ? dj[RM::kSub - 1] : dj[0];
                     }
@@ -1143,7 +1156,7 @@ __global__ __launch_bounds__(NBUF == 2 ? 64 : 128) __attribute__((amdgpu_waves_p
                     // Admission in list order (src/hnsw.cpp:765-777).  A neighbour that fails
                     // `dist < f` against the f at the start of the expansion can only be admitted
                     // while W is not full; f never grows once W is full, so skipping the others is exact.
-                    unsigned long long todo = __ballot(fresh && (dm < f || nW < ef));
+                    unsigned long long todo = __ballot(fresh_b && (dm < f || nW < ef));
                     const uint32_t c_room = nC + (uint32_t)__popcll(todo);      // what the heap must have room for
                     if (c_room > a.cap_c) { fail = 2; break; }
                     c_need = c_room > c_need ? c_room : c_need;
@@ -1155,7 +1168,7 @@ __global__ __launch_bounds__(NBUF == 2 ? 64 : 128) __attribute__((amdgpu_waves_p
                             todo &= todo - 1;
                             const uint32_t db = __builtin_amdgcn_readlane(__float_as_uint(dm), j);
                             if (__uint_as_float(db) < f) {
-                                const uint32_t id = __builtin_amdgcn_readlane(my, j);
+                                const uint32_t id = __builtin_amdgcn_readlane(my_b, j);
                                 const uint2 ce = make_uint2(__builtin_amdgcn_readlane(keym, j), id);
                                 nC++;
                                 const uint2 anc = heap_push_read<COrder>(C, nC, lane);      // in flight during the insert into W
@@ -1176,7 +1189,7 @@ __global__ __launch_bounds__(NBUF == 2 ? 64 : 128) __attribute__((amdgpu_waves_p
                         todo &= todo - 1;
                         const float dist = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(dm), j));
                         if (dist < f || nW < ef) {
-                            const uint32_t id = __builtin_amdgcn_readlane(my, j);
+                            const uint32_t id = __builtin_amdgcn_readlane(my_b, j);
                             const uint2 ce = make_uint2(__builtin_amdgcn_readlane(keym, j), id);
                             const uint2 we = make_uint2(__float_as_uint(dist), id);
                             nC++;
