@@ -614,6 +614,12 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    # a run whose results are not the reference's is a failed run, whatever it measured: the line above is printed
+    # for the record, the exit status says so
+    if rank == 0 and cpu is not None and (cpu.get("parity") is False or cpu.get("precision_within_0.001") is False
+                                          or cpu.get("gpu_distances_bit_equal_on_sample") is False):
+        log("FAILED: results differ from the reference's (see cpu_baseline in the line above)")
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -55,6 +55,10 @@ SYMBOLS = {
                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _u32p]),
     "hnsw_amd_search_batch_device_noalloc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32,
                                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _u32p]),
+    "hnsw_amd_search_batch_device_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32,
+                                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "hnsw_amd_search_batch_device_finish": (C.c_int, [C.c_void_p, C.c_void_p, _u32p]),
+    "hnsw_amd_reload_env": (C.c_int, [C.c_void_p]),
     "hnsw_amd_save_graph": (C.c_int, [C.c_void_p, C.c_char_p]),
     "hnsw_amd_load_graph": (C.c_int, [C.c_void_p, C.c_char_p]),
     "hnsw_amd_import_flat": (C.c_int, [C.c_void_p, C.POINTER(FlatGraphC), _f32p]),

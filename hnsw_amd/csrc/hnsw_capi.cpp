@@ -62,8 +62,16 @@ static int guarded(F&& f)
 #define REQUIRE(cond, msg) do { if (!(cond)) throw std::invalid_argument(msg); } while (0)
 #define HIP_OK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) throw std::runtime_error(std::string("HIP: ") + #expr + ": " + hipGetErrorString(e_)); } while (0)
 
+// The device holds this index's own rows (same table contents, same count): only the graph can have changed.
+static bool device_has_rows(const hnsw_amd_index* h)
+{
+    return h->dev.device == h->device && h->dev.g.vectors && h->dev.rows_epoch == h->host.rows_epoch_ &&
+           h->dev.g.n == h->host.size() && h->dev.g.d == h->host.vector_size_;
+}
+
 static void ensure_device_copy(hnsw_amd_index* h, uint32_t flags = 0)
 {
+    if (h->host.build_failed_) throw std::logic_error("search: an earlier concurrent build failed half way; init() the index again");
     if (h->dev.device != h->device || h->dev.version != h->host.version_) h->dev.upload(h->host, h->device);
     if (flags & HNSW_AMD_ROWS_Q8) h->dev.ensure_quantized(h->host);
 }
@@ -116,8 +124,7 @@ int hnsw_amd_insert_batch(hnsw_amd_index* h, const float* rows, uint32_t n, int 
 static void assisted_candidates(void* ctx, const float* queries, uint32_t nq, int ef, uint32_t* ids, float* dist, uint32_t* cnt)
 {
     hnsw_amd_index* h = static_cast<hnsw_amd_index*>(ctx);
-    const bool same_rows = h->dev.device == h->device && h->dev.g.vectors && h->dev.g.n == h->host.size() && h->dev.g.d == h->host.vector_size_;
-    if (same_rows) h->dev.refresh_graph(h->host);
+    if (device_has_rows(h)) h->dev.refresh_graph(h->host);
     else h->dev.upload(h->host, h->device);
     const uint32_t flags = HNSW_AMD_DIST_SSE | (h->host.build_float_keys_ ? HNSW_AMD_KEYS_FLOAT : HNSW_AMD_KEYS_INT32);
     const int rc = hnsw_amd_search_batch(h, queries, nq, ef, (uint32_t)ef, flags, ids, dist, cnt, nullptr);
@@ -135,9 +142,7 @@ int hnsw_amd_insert_batch_assisted(hnsw_amd_index* h, const float* rows, uint32_
         h->host.insert_batch(rows, n, threads, assisted_candidates, h);
         // the device holds every row already: bring its graph to the final state instead of leaving a full upload to
         // the first search
-        if (h->dev.device == h->device && h->dev.g.vectors && h->dev.g.n == h->host.size() && h->dev.g.d == h->host.vector_size_ &&
-            h->dev.version != h->host.version_)
-            h->dev.refresh_graph(h->host);
+        if (device_has_rows(h) && h->dev.version != h->host.version_) h->dev.refresh_graph(h->host);
     });
 }
 
@@ -165,9 +170,35 @@ int hnsw_amd_search_batch_device(hnsw_amd_index* h, const float* d_queries, uint
     return guarded([&] {
         REQUIRE(h && d_queries && d_out_ids && d_out_dist, "search_batch_device: NULL argument");
         ensure_device_copy(h, flags);
-        uint32_t r = h->dev.search(d_queries, nq, ef, out_k, flags, d_out_ids, d_out_dist, d_out_count, d_stats, stream, true);
+        uint32_t r = h->dev.search(d_queries, nq, ef, out_k, flags, d_out_ids, d_out_dist, d_out_count, d_stats, stream);
         if (retried) *retried = r;
     });
+}
+
+int hnsw_amd_search_batch_device_begin(hnsw_amd_index* h, const float* d_queries, uint32_t nq, int ef, uint32_t out_k,
+                                       uint32_t flags, uint32_t* d_out_ids, float* d_out_dist, uint32_t* d_out_count,
+                                       hnsw_amd_query_stats* d_stats, void* stream, hnsw_amd_search_call** call)
+{
+    return guarded([&] {
+        REQUIRE(h && d_queries && d_out_ids && d_out_dist && call, "search_batch_device_begin: NULL argument");
+        *call = nullptr;
+        ensure_device_copy(h, flags);
+        *call = reinterpret_cast<hnsw_amd_search_call*>(h->dev.begin(d_queries, nq, ef, out_k, flags, d_out_ids, d_out_dist, d_out_count, d_stats, stream));
+    });
+}
+
+int hnsw_amd_search_batch_device_finish(hnsw_amd_index* h, hnsw_amd_search_call* call, uint32_t* retried)
+{
+    return guarded([&] {
+        REQUIRE(h && call, "search_batch_device_finish: NULL argument");
+        uint32_t r = h->dev.finish(reinterpret_cast<SearchCall*>(call));
+        if (retried) *retried = r;
+    });
+}
+
+int hnsw_amd_reload_env(hnsw_amd_index* h)
+{
+    return guarded([&] { REQUIRE(h, "reload_env: index is NULL"); h->dev.tune.read(); });
 }
 
 int hnsw_amd_search_batch_device_noalloc(hnsw_amd_index* h, const float* d_queries, uint32_t nq, int ef, uint32_t out_k,
@@ -181,7 +212,7 @@ int hnsw_amd_search_batch_device_noalloc(hnsw_amd_index* h, const float* d_queri
                 "search_batch_device_noalloc: the index is not on the device (or changed since): call hnsw_amd_sync_device first");
         REQUIRE(!(flags & HNSW_AMD_ROWS_Q8) || h->dev.g.vectors_q8 != nullptr,
                 "search_batch_device_noalloc: HNSW_AMD_ROWS_Q8 needs the quantised table, which an allocating search call builds on first use");
-        uint32_t r = h->dev.search(d_queries, nq, ef, out_k, flags, d_out_ids, d_out_dist, d_out_count, d_stats, stream, true, true);
+        uint32_t r = h->dev.search(d_queries, nq, ef, out_k, flags, d_out_ids, d_out_dist, d_out_count, d_stats, stream, true);
         if (retried) *retried = r;
     });
 }
@@ -218,7 +249,7 @@ int hnsw_amd_search_batch(hnsw_amd_index* h, const float* queries, uint32_t nq, 
         // the results travel back behind every launch of the call, ahead of the wait that learns whether a launch
         // has to be repeated for some queries (rare); the last copy is the one that counts
         const DeviceIndex::CopyBack back{h->h_out, h->d_out, stats ? ob : ob - (size_t)nq * sizeof(hnsw_amd_query_stats)};
-        h->dev.search((const float*)h->d_q, nq, ef, out_k, flags, d_ids, d_dist, d_cnt, stats ? d_stats : nullptr, nullptr, true, false, &back);
+        h->dev.search((const float*)h->d_q, nq, ef, out_k, flags, d_ids, d_dist, d_cnt, stats ? d_stats : nullptr, nullptr, false, &back);
         const uint32_t* r = static_cast<const uint32_t*>(h->h_out);
         std::memcpy(out_ids, r, oe * 4);
         std::memcpy(out_dist, r + oe, oe * 4);

@@ -3,6 +3,8 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <utility>
+#include <vector>
 
 #include "../../include/hnsw_amd.h"
 #include "hnsw_host.h"
@@ -55,6 +57,39 @@ struct SearchArgs {
 
 size_t search_lds_bytes(const SearchArgs& a, bool w_in_lds);
 
+// Developer switches read from the environment (HNSW_AMD_*; see Tunables::read for each), once per upload of an index
+// and on hnsw_amd_reload_env — never inside a search call.
+struct Tunables {
+    bool generic_rows = false, no_deep_rows = false, visited32 = false, visited16 = false, visitedb = false, no_spill = false, verbose = false;
+    bool no_pack_c = false, no_dot4 = false;
+    float bulk_frac = 0.30f;
+    long want_visit = -1, want_bulk = -1, spill_tables = -1, rb_min = 0, lds_budget = -1, lds_pad = 0;
+    void read();
+};
+
+// A search call between its begin and its finish: everything the call owns (the retry protocol's two lists of
+// overflowed queries, the pinned words its launches report into, its pool of spill tables) and what finish needs to
+// know about it.  An index keeps a few of these, so that as many calls can be in flight on it at once.
+struct SearchCall {
+    bool busy = false;
+    uint32_t* d_lists = nullptr;      // two lists of list_cap words each: kFailHeader words of header, then query indices
+    uint32_t list_cap = 0;
+    uint32_t* h_report = nullptr;     // pinned host mirror of a list's header
+    uint32_t* d_spill = nullptr;      // pool of spill tables (bucket form of the visited set), allocated on first need
+    // the call
+    SearchArgs a{};
+    uint32_t nq = 0, flags = 0, retried = 0;
+    int ef = 0, tier = 0;
+    bool no_alloc = false, launched = false, timed = false, has_copy_back = false;
+    void* stream = nullptr;
+    uint32_t *cur = nullptr, *other = nullptr;        // the list the current launch appends to, and the other one
+    uint32_t want_visit0 = 0, want_c0 = 0, want_bulk0 = 0;
+    uint32_t seen_visit = 0, seen_c = 0;
+    uint64_t seen_sum16 = 0, seen_done = 0;
+    struct { void* dst; const void* src; size_t bytes; } copy_back{};
+    void *ev0 = nullptr, *ev1 = nullptr;              // (verbose) events around the kernel
+};
+
 struct BucketShape {
     uint32_t n = 0, want = 0, rb_min = 0;     // what it was computed for
     uint32_t regions = 0, chunks = 0, ovf = 0;
@@ -65,16 +100,14 @@ class DeviceIndex {
 public:
     int device = -1;
     uint64_t version = ~0ull;     // HostIndex::version_ this copy was made from
+    uint64_t rows_epoch = 0;      // HostIndex::rows_epoch_ of the vector table that was uploaded
     DeviceGraph g{};
-    // scratch for the retry protocol
-    uint32_t* d_fail = nullptr;       // [0] = count, [1..] list
-    uint32_t fail_cap = 0;
-    uint32_t* h_fail = nullptr;       // pinned host mirror of the list header
+    static constexpr int kMaxCallsInFlight = 4;
+    Tunables tune;
     struct OccupancyNote { const void* kernel; size_t bytes; int blocks; };
     std::vector<OccupancyNote> occupancy_notes;   // resident workgroups per CU the runtime reported, by kernel and LDS size
     uint32_t learn_age = 0;           // batches since the sizes were learned
     int dev_max_lds = 0, dev_num_cus = 0;   // device attributes, looked up once
-    uint32_t* d_spill = nullptr;      // pool of spill tables (bucket form of the visited set), allocated on first need
     // largest visited set and candidate heap the queries of earlier batches reached, and the ef / flags they were
     // observed at: later batches are sized from them
     uint32_t learn_flags = 0;
@@ -108,13 +141,28 @@ public:
     // vector table with the search kernel's loads and distance arithmetic and nothing else; `bytes` = what the
     // search's counters would charge for those rows.  lds_bytes per wavefront sets the residency.
     float gather_ceiling(uint32_t n_waves, uint32_t rows_per_wave, uint32_t lds_bytes, void* stream, uint64_t& bytes);
-    // copy_back: a device-to-host copy (pinned destination) queued behind every launch, before the wait.
-    struct CopyBack { void* dst; const void* src; size_t bytes; };
+    // copy_back: a device-to-host copy (pinned destination) queued behind every launch, before the report.
+    typedef decltype(SearchCall::copy_back) CopyBack;
+    // begin: sizes the batch's scratch from what is known, launches it on `stream` and queues the launch's report; returns
+    // without waiting.  finish: waits for the report, re-runs the queries that outgrew their scratch on larger tables
+    // (waiting for each such launch), remembers what the batch needed; returns the number of re-run queries.  Up to
+    // kMaxCallsInFlight calls may be between begin and finish on one index at a time; they finish in any order.
+    SearchCall* begin(const float* d_queries, uint32_t nq, int ef, uint32_t out_k, uint32_t flags, uint32_t* d_ids,
+                      float* d_dist, uint32_t* d_count, hnsw_amd_query_stats* d_stats, void* stream,
+                      bool no_alloc = false, const CopyBack* copy_back = nullptr);
+    uint32_t finish(SearchCall* call);
     uint32_t search(const float* d_queries, uint32_t nq, int ef, uint32_t out_k, uint32_t flags, uint32_t* d_ids,
-                    float* d_dist, uint32_t* d_count, hnsw_amd_query_stats* d_stats, void* stream, bool sync_and_retry,
+                    float* d_dist, uint32_t* d_count, hnsw_amd_query_stats* d_stats, void* stream,
                     bool no_alloc = false, const CopyBack* copy_back = nullptr);
+    bool calls_in_flight() const;
 
 private:
+    void launch_tier(SearchCall& c);
+    void wait_report(SearchCall& c);
+    void set_max_dynamic_lds(const void* kernel, size_t lds);
+    SearchCall calls_[kMaxCallsInFlight];
+    SearchCall noalloc_call_;          // the entry point that allocates nothing: lists in the library's static device array
+    std::vector<std::pair<const void*, size_t>> func_lds_;    // largest dynamic LDS size each kernel was enabled for
     void* bufs_[8] = {};
 };
 

@@ -148,6 +148,8 @@ HostIndex::HostIndex(int M, int Mmax, int efConstruction)
 
 HostIndex::~HostIndex() = default;
 
+static std::atomic<uint64_t> g_rows_epoch{0};
+
 void HostIndex::init(uint32_t vector_size, uint32_t max_node_count)
 {
     if (vector_size == 0) throw std::invalid_argument("init: vector_size must be positive");
@@ -157,6 +159,8 @@ void HostIndex::init(uint32_t vector_size, uint32_t max_node_count)
     layers_.clear();
     actual_node_count_ = -1;
     rng_ = std::make_unique<GlibcRand>(1);
+    rows_epoch_ = ++g_rows_epoch;
+    build_failed_ = false;
     version_++;
 }
 
@@ -412,6 +416,7 @@ void HostIndex::insert_one(uint32_t id, const float* q, int level, const uint32_
 void HostIndex::insert(const float* q)
 {
     if (max_node_count_ <= 0) throw std::invalid_argument("insert: init() has not been called");
+    if (build_failed_) throw std::logic_error("insert: an earlier concurrent build failed half way; init() the index again");
     // the reference draws the level before it checks capacity (src/hnsw.cpp:165,175-179)
     int level = draw_level();
     if (actual_node_count_ + 1 >= max_node_count_) throw std::runtime_error("HNSW: exceeded maximal number of nodes\n");
@@ -438,6 +443,7 @@ void HostIndex::ensure_locks()
 void HostIndex::insert_batch(const float* rows, uint32_t n, int threads, CandidateSearchFn candidates, void* ctx)
 {
     if (max_node_count_ <= 0) throw std::invalid_argument("insert_batch: init() has not been called");
+    if (build_failed_) throw std::logic_error("insert_batch: an earlier concurrent build failed half way; init() the index again");
     if ((int64_t)actual_node_count_ + 1 + n > (int64_t)max_node_count_)
         throw std::runtime_error("HNSW: exceeded maximal number of nodes\n");
     if (threads <= 1 || n < 2048) {
@@ -481,8 +487,11 @@ void HostIndex::insert_batch(const float* rows, uint32_t n, int threads, Candida
             Ls.reserve_nodes(total);
         }
     }
-    // Process in segments separated by layer-raising vectors.
+    // Process in segments separated by layer-raising vectors.  If anything throws from here on (the candidate
+    // searches can: device memory, a HIP error) the segment's nodes are in the layers but not all linked: the index
+    // is marked as failed, and the version moves so that no device copy passes for current.
     uint32_t seg_begin = warm;
+    try {
     while (seg_begin < n) {
         uint32_t seg_end = seg_begin;
         while (seg_end < n && !raises[seg_end]) seg_end++;
@@ -540,11 +549,12 @@ void HostIndex::insert_batch(const float* rows, uint32_t n, int threads, Candida
                 run_range(seg_begin, seg_end, nullptr, nullptr, nullptr);
             } else {
                 // Candidate lists from outside (the GPU): the graph is frozen while a sub-batch is searched, so the vectors
-                // of a sub-batch do not see each other; sub-batches stay below an eighth of what is linked already.
+                // of a sub-batch do not see each other; sub-batches stay small next to what is linked already.
                 std::vector<uint32_t> cids, ccnt; std::vector<float> cdist;
                 for (uint32_t pos = seg_begin; pos < seg_end;) {
                     const uint32_t linked = first + pos;
-                    const uint32_t want = std::min<uint32_t>(16384u, std::max<uint32_t>(1024u, linked / 16u));
+                    // (a sixteenth of what is linked, 16384 at most; while the graph is small a quarter of it, up to 1024)
+                    const uint32_t want = std::min<uint32_t>(16384u, std::max<uint32_t>(std::min<uint32_t>(1024u, std::max<uint32_t>(64u, linked / 4u)), linked / 16u));
                     const uint32_t end = std::min<uint32_t>(seg_end, pos + want);
                     const uint32_t cnt = end - pos;
                     cids.resize((size_t)cnt * efConstruction_); cdist.resize((size_t)cnt * efConstruction_); ccnt.assign(cnt, 0);
@@ -569,6 +579,11 @@ void HostIndex::insert_batch(const float* rows, uint32_t n, int threads, Candida
             seg_end++;
         }
         seg_begin = seg_end;
+    }
+    } catch (...) {
+        build_failed_ = true;
+        version_++;
+        throw;
     }
     actual_node_count_ = (int)(first + n - 1);
     version_++;
@@ -748,6 +763,8 @@ void HostIndex::load_graph(const char* filename)
     vector_size_ = tmp.vector_size_; max_node_count_ = tmp.max_node_count_; actual_node_count_ = tmp.actual_node_count_;
     layers_ = std::move(tmp.layers_);
     vector_data_ = std::move(tmp.vector_data_);
+    rows_epoch_ = tmp.rows_epoch_;      // (unique in the process: tmp's init drew it)
+    build_failed_ = false;
     rng_ = std::make_unique<GlibcRand>(1);
     locks_.clear(); lock_cap_.clear();
     version_++;

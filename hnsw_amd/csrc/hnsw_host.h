@@ -62,6 +62,10 @@ public:
     std::vector<float> vector_data_;   // max_node_count_ x vector_size_, row = node_order
     bool build_float_keys_ = false;    // construction searches keyed by the float distance instead of its int32 truncation
     uint64_t version_ = 0;             // bumped by every mutation (device copy refresh)
+    uint64_t rows_epoch_ = 0;          // identifies the contents of vector_data_'s table: a new value (unique in the process) whenever
+                                       // init / load_graph / import_flat replaces it, so a device copy of the rows knows whose rows it holds
+    bool build_failed_ = false;        // a concurrent build stopped half way (nodes added, not all linked): searches and inserts refuse until
+                                       // init / load_graph / import_flat starts over
     double assisted_search_s = 0.0, assisted_link_s = 0.0;   // where an assisted build's time went (HNSW_AMD_VERBOSE prints them)
     uint32_t assisted_batches = 0;
 

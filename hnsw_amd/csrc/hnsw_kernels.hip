@@ -24,7 +24,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <atomic>
+#include <chrono>
 #include <mutex>
+#include <thread>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -1463,19 +1465,35 @@ size_t search_lds_bytes(const SearchArgs& a, bool w_in_lds)
 }
 
 // ---------------------------------------------------------------------------------------
-DeviceIndex::~DeviceIndex() { release(); }
+DeviceIndex::~DeviceIndex()
+{
+    // (a destructor cannot refuse: calls still in flight are abandoned)
+    for (SearchCall& c : calls_) c.busy = false;
+    noalloc_call_.busy = false;
+    release();
+}
 
 void DeviceIndex::release()
 {
+    if (calls_in_flight()) throw std::logic_error("the index was changed (or destroyed) while a search call on it was in flight: finish the call first");
     if (device >= 0) (void)hipSetDevice(device);
     for (auto& b : bufs_) { if (b) (void)hipFree(b); b = nullptr; }
-    if (d_fail) (void)hipFree(d_fail);
-    if (d_spill) (void)hipFree(d_spill);
-    d_spill = nullptr;
-    if (h_fail) (void)hipHostFree(h_fail);
+    auto drop = [](SearchCall& c) {
+        if (c.d_lists) (void)hipFree(c.d_lists);
+        if (c.d_spill) (void)hipFree(c.d_spill);
+        if (c.h_report) (void)hipHostFree(c.h_report);
+        c = SearchCall{};
+    };
+    for (SearchCall& c : calls_) drop(c);
+    noalloc_call_.d_spill = nullptr;          // (borrowed, never owned)
+    drop(noalloc_call_);
+    version = ~0ull; rows_epoch = 0;
+}
 
-    d_fail = nullptr; h_fail = nullptr; fail_cap = 0;
-    version = ~0ull;
+bool DeviceIndex::calls_in_flight() const
+{
+    for (const SearchCall& c : calls_) if (c.busy) return true;
+    return noalloc_call_.busy;
 }
 
 template <class T>
@@ -1549,9 +1567,12 @@ void DeviceIndex::upload(const HostIndex& h, int dev)
     HIP_CHECK(hipDeviceSynchronize());
     // set-up for the search calls: the pinned word the overflow count is read into, and this GPU's address of the
     // static scratch array (so that a search call itself never has to allocate or look anything up)
-    if (!h_fail) HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_fail), 64, hipHostMallocDefault));
+    if (!noalloc_call_.h_report) HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&noalloc_call_.h_report), 64, hipHostMallocDefault));
     (void)noalloc_scratch_for(dev, true);
+    tune.read();
+    func_lds_.clear();
     version = h.version_;
+    rows_epoch = h.rows_epoch_;
     learn_flags = 0; learn_ef = 0; learn_visit = 0; learn_c = 0; learn_mean = 0; learn_notes.clear();
     shape_full = BucketShape{}; shape_bulk = BucketShape{};
 }
@@ -1704,9 +1725,8 @@ static SearchKernel pick_rows(bool scalar, int wr, int rows, bool ip, int nl)
 }
 
 // deep: the float-row, probing-form kernel with six row pieces in flight and two wavefronts per query (see hnsw_search_kernel)
-static SearchKernel pick_kernel(bool scalar, int wr, int rows, bool bucket, bool ip, uint32_t d, bool deep = false)
+static SearchKernel pick_kernel(bool scalar, int wr, int rows, bool bucket, bool ip, uint32_t d, bool generic /* the kernel for any row length */, bool deep = false)
 {
-    const bool generic = getenv("HNSW_AMD_GENERIC_ROWS") != nullptr;                      // (diagnostics: the kernel for any row length)
     if (deep && !scalar && rows == 0 && !bucket && !ip) {
         // (960 used dims = seven whole 128-dim items and one of four loads: the shape of the configuration this form exists for)
         if (!generic && (d & ~15u) == 960u) return pick_wr<false, 0, false, 6, false, 704>(wr);
@@ -1778,43 +1798,100 @@ static bool bucket_shape(uint32_t n, uint32_t want_visit, uint32_t rb_min, uint3
     return best != ~(size_t)0;
 }
 
-// Spill tables of the bucket form (device memory): a pool per index, 64 MB
+// Spill tables of the bucket form (device memory): a pool of 64 MB per search call in flight
 constexpr uint32_t kSpillTables = 1024, kSpillSlots = 16384;
 
-uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32_t out_k, uint32_t flags, uint32_t* d_ids,
-                             float* d_dist, uint32_t* d_count, hnsw_amd_query_stats* d_stats, void* stream_v, bool sync_and_retry,
-                             bool no_alloc, const CopyBack* copy_back)
+// The switches a developer can set in the environment (diagnostics, tests, tuning; the C ABI has no knob for them).
+// Read when an index is put on a device and again by hnsw_amd_reload_env, never inside a search call.
+void Tunables::read()
+{
+    auto on = [](const char* name) { return getenv(name) != nullptr; };
+    auto num = [](const char* name, long dflt) { const char* e = getenv(name); return e ? atol(e) : dflt; };
+    generic_rows = on("HNSW_AMD_GENERIC_ROWS");      // the kernel for any row length instead of the one built for the row shape
+    no_deep_rows = on("HNSW_AMD_NO_DEEP_ROWS");      // never the two-wavefront form
+    visited32 = on("HNSW_AMD_VISITED32"); visited16 = on("HNSW_AMD_VISITED16"); visitedb = on("HNSW_AMD_VISITEDB");   // force one form of the visited set
+    no_spill = on("HNSW_AMD_NO_SPILL");              // bucket form without spill tables
+    verbose = on("HNSW_AMD_VERBOSE");                // launch configuration and kernel times on stderr
+    no_pack_c = on("HNSW_AMD_NO_PACK_C");            // candidate heap entries of 8 bytes even where 4 would do
+    no_dot4 = on("HNSW_AMD_NO_DOT4");                // byte rows through the float arithmetic even where integer dot products are exact
+    const char* bf = getenv("HNSW_AMD_BULK_FRAC");
+    bulk_frac = bf ? (float)atof(bf) : 0.30f;        // (0.45 and 0.30 measure alike on the SIFT-shaped set; 0.30 lets the 12.5 M-row DEEP-shaped shard hold more queries per CU)
+    want_visit = num("HNSW_AMD_WANT_VISIT", -1);     // a fixed size of the visited set
+    want_bulk = num("HNSW_AMD_WANT_BULK", -1);       // tests: spill whatever it gains
+    spill_tables = num("HNSW_AMD_SPILL_TABLES", -1); // tests: a pool that runs dry
+    rb_min = num("HNSW_AMD_VIS_RB_MIN", 0);          // tests: the region count of a larger index
+    lds_budget = num("HNSW_AMD_LDS_BUDGET", -1);     // tests: bare estimates
+    lds_pad = num("HNSW_AMD_LDS_PAD", 0);            // occupancy experiments
+}
+
+void DeviceIndex::set_max_dynamic_lds(const void* kern, size_t lds)
+{
+    if (lds <= 32768) return;
+    for (auto& f : func_lds_) if (f.first == kern) {
+        if (f.second >= lds) return;
+        HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        f.second = lds;
+        return;
+    }
+    HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    func_lds_.emplace_back(kern, lds);
+}
+
+// ---- one search call = begin (size the scratch from what is known, launch, queue the report) + finish (wait for the
+//      report, re-run what outgrew its scratch on larger tables, remember what the batch needed) ----
+
+SearchCall* DeviceIndex::begin(const float* d_queries, uint32_t nq, int ef, uint32_t out_k, uint32_t flags, uint32_t* d_ids,
+                               float* d_dist, uint32_t* d_count, hnsw_amd_query_stats* d_stats, void* stream_v,
+                               bool no_alloc, const CopyBack* copy_back)
 {
     if (device < 0) throw std::logic_error("search: index not on a device");
     if (no_alloc && nq > kNoAllocMaxQueries)
         throw std::invalid_argument("search (no-allocation entry point): at most " + std::to_string(kNoAllocMaxQueries) +
                                     " queries per call, got " + std::to_string(nq));
-    if (nq == 0) return 0;
-    if (ef < 1 || out_k < 1 || out_k > (uint32_t)ef) throw std::invalid_argument("search: need 1 <= out_k <= ef");
-    if (ef > (1 << 20)) throw std::length_error("search: ef beyond anything the on-chip scratch can hold");   // (and the size estimates stay in range)
+    if (nq != 0) {
+        if (ef < 1 || out_k < 1 || out_k > (uint32_t)ef) throw std::invalid_argument("search: need 1 <= out_k <= ef");
+        if (ef > (1 << 20)) throw std::length_error("search: ef beyond anything the on-chip scratch can hold");   // (and the size estimates stay in range)
+    }
+    SearchCall* cp = nullptr;
+    if (no_alloc) {
+        cp = &noalloc_call_;
+        if (cp->busy) throw std::logic_error("search (no-allocation entry point): the previous call has not finished");
+    } else {
+        for (SearchCall& c : calls_) if (!c.busy) { cp = &c; break; }
+        if (!cp) throw std::logic_error("search: " + std::to_string(kMaxCallsInFlight) + " calls are in flight on this index already; finish one first");
+    }
+    SearchCall& c = *cp;
+    c.nq = nq; c.ef = ef; c.flags = flags; c.no_alloc = no_alloc; c.retried = 0; c.tier = 0; c.launched = false;
+    c.seen_visit = 0; c.seen_c = 0; c.seen_sum16 = 0; c.seen_done = 0;
+    c.has_copy_back = copy_back != nullptr;
+    if (copy_back) c.copy_back = *copy_back;
+    c.stream = stream_v;
+    if (nq == 0) { c.busy = true; return cp; }
     HIP_CHECK(hipSetDevice(device));
-    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
     // the two overflow lists (kFailHeader words of header, then query indices): a retry launch reads one and
     // appends to the other
-    uint32_t* list_a = nullptr;
-    uint32_t* list_b = nullptr;
     if (no_alloc) {
         // this GPU's copy of the static scratch array, through the address looked up at upload (never the array's name)
-        list_a = noalloc_scratch_for(device, false);
-        if (!list_a || !h_fail) throw std::logic_error("search (no-allocation entry point): the index was not set up on this device");
-        list_b = list_a + (kNoAllocMaxQueries + kFailHeader);
+        uint32_t* lists = noalloc_scratch_for(device, false);
+        if (!lists || !c.h_report) throw std::logic_error("search (no-allocation entry point): the index was not set up on this device");
+        c.cur = lists;
+        c.other = lists + (kNoAllocMaxQueries + kFailHeader);
+        // (spill tables only if an allocating call left a pool behind that nobody is using now)
+        c.d_spill = calls_[0].busy ? nullptr : calls_[0].d_spill;
     } else {
-        if (fail_cap < nq + kFailHeader) {
-            if (d_fail) HIP_CHECK(hipFree(d_fail));
-            d_fail = nullptr;
-            HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_fail), ((size_t)nq + kFailHeader) * 4 * 2));
-            fail_cap = nq + kFailHeader;
+        if (c.list_cap < nq + kFailHeader) {
+            if (c.d_lists) HIP_CHECK(hipFree(c.d_lists));
+            c.d_lists = nullptr; c.list_cap = 0;
+            HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&c.d_lists), ((size_t)nq + kFailHeader) * 4 * 2));
+            c.list_cap = nq + kFailHeader;
         }
-        list_a = d_fail;
-        list_b = d_fail + fail_cap;
+        if (!c.h_report) HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&c.h_report), 64, hipHostMallocDefault));
+        c.cur = c.d_lists;
+        c.other = c.d_lists + c.list_cap;
     }
 
-    SearchArgs a{};
+    SearchArgs& a = c.a;
+    a = SearchArgs{};
     a.g = g; a.queries = d_queries; a.qmap = nullptr; a.nq_launch = nq;
     a.ef = (uint32_t)ef; a.out_k = out_k; a.flags = flags;
     a.cap_w = ((uint32_t)ef + 2u) & ~1u;
@@ -1830,14 +1907,12 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
         throw std::invalid_argument("search: HNSW_AMD_METRIC_IP goes with float rows and HNSW_AMD_DIST_SSE only");
     a.qpad = (u8 || q8) ? ((g.d + 127u) & ~127u) : ((g.d + 63u) & ~63u);
     a.out_ids = d_ids; a.out_dist = d_dist; a.out_count = d_count; a.stats = d_stats;
-    const bool scalar = (flags & HNSW_AMD_DIST_SCALAR) != 0;
 
     if (dev_max_lds == 0) {
         HIP_CHECK(hipDeviceGetAttribute(&dev_max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device));
         HIP_CHECK(hipDeviceGetAttribute(&dev_num_cus, hipDeviceAttributeMultiprocessorCount, device));
         if (dev_num_cus < 1) dev_num_cus = 1;
     }
-    const int max_lds = dev_max_lds, num_cus = dev_num_cus;
 
     // ---- what the queries of this batch are expected to need ----
     // Sized from what earlier batches on this index were seen to need (the kernel reports the largest visited
@@ -1865,198 +1940,248 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
         // (nothing on this kind yet: with the same flags the last kind's figures, scaled, are the first guess)
         if (!found && flags != learn_flags) { learn_flags = flags; learn_ef = 0; learn_visit = 0; learn_c = 0; learn_mean = 0; }
     }
-    uint32_t want_visit0 = visit_estimate(ef), want_c0 = heap_estimate(ef);
+    c.want_visit0 = visit_estimate(ef); c.want_c0 = heap_estimate(ef);
     a.known_visit = 0; a.known_c = 0;
     // what the bulk of the queries needs (bucket form with spill tables: the few beyond it continue in device memory)
-    uint32_t want_bulk0 = 0;
+    c.want_bulk0 = 0;
     if (learn_ef == ef) {
-        float frac = 0.30f;         // (0.45 and 0.30 measure alike on the SIFT-shaped set; 0.30 lets the 12.5 M-row DEEP-shaped shard hold 12 queries per CU instead of 11: 2.54 -> 2.46 ms)
-        if (const char* e = getenv("HNSW_AMD_BULK_FRAC")) frac = (float)atof(e);      // tuning
-        if (learn_mean > 0 && learn_mean < learn_visit) want_bulk0 = learn_mean + (uint32_t)(frac * (float)(learn_visit - learn_mean));
-        want_visit0 = learn_visit + learn_visit / 20u + 16u;
+        if (learn_mean > 0 && learn_mean < learn_visit) c.want_bulk0 = learn_mean + (uint32_t)(tune.bulk_frac * (float)(learn_visit - learn_mean));
+        c.want_visit0 = learn_visit + learn_visit / 20u + 16u;
         // (queries report only what goes beyond what is known; one batch in 64 reports in full, so that the known
         // values can also come down)
         if ((++learn_age & 63u) != 0u) { a.known_visit = learn_visit; a.known_c = learn_c; }
-        want_c0 = learn_c + learn_c / 32u + 4u;          // (learn_c is what the overflow test asked for, not the heap's size)
+        c.want_c0 = learn_c + learn_c / 32u + 4u;          // (learn_c is what the overflow test asked for, not the heap's size)
     } else if (learn_ef != 0) {
         const float rv = std::max(1.0f, 1.2f * (float)learn_visit / (float)visit_estimate(learn_ef));
         const float rc = std::max(1.0f, 1.2f * (float)learn_c / (float)heap_estimate(learn_ef));
-        want_visit0 = (uint32_t)((float)want_visit0 * std::min(rv, 16.0f));
-        want_c0 = (uint32_t)((float)want_c0 * std::min(rc, 16.0f));
+        c.want_visit0 = (uint32_t)((float)c.want_visit0 * std::min(rv, 16.0f));
+        c.want_c0 = (uint32_t)((float)c.want_c0 * std::min(rc, 16.0f));
     }
-    if (const char* e = getenv("HNSW_AMD_WANT_VISIT")) want_visit0 = (uint32_t)atoi(e);      // diagnostics: a fixed size
-    const char* force_bulk = getenv("HNSW_AMD_WANT_BULK");                                   // tests: spill whatever it gains
-    if (force_bulk) want_bulk0 = (uint32_t)atoi(force_bulk);
-    uint32_t spill_tables = kSpillTables;
-    if (const char* e = getenv("HNSW_AMD_SPILL_TABLES")) spill_tables = std::min<uint32_t>(kSpillTables, (uint32_t)atoi(e));   // tests: a pool that runs dry
-    uint32_t rb_min = 0;
-    if (const char* e = getenv("HNSW_AMD_VIS_RB_MIN")) rb_min = (uint32_t)atoi(e);      // tests: the region count of a larger index
+    if (tune.want_visit >= 0) c.want_visit0 = (uint32_t)tune.want_visit;
+    if (tune.want_bulk >= 0) c.want_bulk0 = (uint32_t)tune.want_bulk;
+    c.busy = true;
+    try {
+        launch_tier(c);
+    } catch (...) {
+        c.busy = false;
+        throw;
+    }
+    return cp;
+}
 
-    uint32_t retried = 0;
-    uint32_t* cur = list_a;
-    uint32_t* other = list_b;
-    uint32_t seen_visit = 0, seen_c = 0;
-    uint64_t seen_sum16 = 0, seen_done = 0;
-    for (int tier = 0;; tier++) {
-        const uint32_t want_visit = want_visit0 << tier;
-        a.spill_pool = nullptr; a.spill_tables = 0; a.spill_slots = 0; a.vis_regions = 0; a.vis_magic = 0;
-        a.hash_size = hash32_slots(want_visit); a.vis_rb = 0xFFFFFFFFu; a.vis_chunks = 0; a.ovf_size = 0;
-        a.cap_c = std::max(((want_c0 << tier) + 31u) & ~31u, ((uint32_t)ef + 33u) & ~31u);      // W is sorted in C's space at the end
-        const bool std_heap = (flags & HNSW_AMD_W_STD_HEAP) != 0 || ef > 256;
-        if (!std_heap && a.cap_w > a.cap_c) throw std::logic_error("search: W does not fit the space it borrows for the final sort");
-        size_t lds = search_lds_bytes(a, std_heap);
-        const int wr = std_heap ? 0 : (ef <= 64 ? 1 : (ef <= 128 ? 2 : 4));
-        // wide rows in a batch that leaves most of the chip idle: more loads in flight per query
-        // (its 240 registers and two wavefronts per query leave a CU four queries: batches of up to four per CU)
-        const bool deep_rows = g.d > 256 && (uint64_t)a.nq_launch <= 4ull * (uint64_t)num_cus && !getenv("HNSW_AMD_NO_DEEP_ROWS");
-        const SearchKernel kern_p = pick_kernel(scalar, wr, u8 ? 1 : (q8 ? 2 : 0), false, ip, g.d, deep_rows);     // probing forms
-        const SearchKernel kern_b = pick_kernel(scalar, wr, u8 ? 1 : (q8 ? 2 : 0), true, ip, g.d);      // bucket form
-        // LDS a query may use without lowering residency: the float-row kernels need 110-118 VGPRs, i.e. 4 waves per
-        // SIMD = 16 one-wave workgroups per CU (the byte-row kernels could run 24, measured no faster than 16), and a
-        // batch of fewer than 16 queries per CU needs even fewer slots (bounded, so that clearing the tables stays cheap).
-        const uint32_t per_cu = std::min<uint32_t>(16u, (a.nq_launch + (uint32_t)num_cus - 1u) / (uint32_t)num_cus);
-        size_t budget = std::min<size_t>(kLdsPerCu / per_cu, 40960);
-        if (const char* cap = getenv("HNSW_AMD_LDS_BUDGET")) budget = std::min<size_t>(budget, (size_t)atol(cap));   // tests: bare estimates
-        // (the deep form runs two wavefronts per query, which talk through a mailbox behind the query's tables)
-        constexpr size_t kMailBytes = 1024;
-        const bool deep_kernel = deep_rows && !scalar && !u8 && !q8 && !ip;
-        if (deep_kernel && budget > 4 * kMailBytes) budget -= kMailBytes;
-        {
-            // 16-bit visited slots where they let a CU hold more queries: the probing form (large regions) or the
-            // bucket form (small regions read whole, nearly full, plus an overflow table), whichever needs less LDS.
-            // HNSW_AMD_VISITED32 / HNSW_AMD_VISITED16 / HNSW_AMD_VISITEDB force one form.
-            const bool force16 = getenv("HNSW_AMD_VISITED16") != nullptr, forceb = getenv("HNSW_AMD_VISITEDB") != nullptr;
-            if (!getenv("HNSW_AMD_VISITED32") && (force16 || forceb || lds > budget)) {
-                auto occupancy = [&](size_t bytes, bool bucket = false) {
-                    if (bytes > 65536) return (int)(kLdsPerCu / bytes);
-                    // (asked of the runtime once per kernel and size: the call costs microseconds, a batch a few hundred)
-                    const void* fn = reinterpret_cast<const void*>(bucket ? kern_b : kern_p);
-                    for (const OccupancyNote& o : occupancy_notes) if (o.kernel == fn && o.bytes == bytes) return o.blocks;
-                    int occ = 0;
-                    HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, 64, bytes));
-                    if (occupancy_notes.size() >= 64) occupancy_notes.clear();
-                    occupancy_notes.push_back({fn, bytes, occ});
-                    return occ;
-                };
-                auto bucket_args = [&](uint32_t want, BucketShape& sh, SearchArgs& out) -> size_t {
-                    if (sh.n != g.n || sh.want != want || sh.rb_min != rb_min) {
-                        sh.ok = bucket_shape(g.n, want, rb_min, sh.regions, sh.chunks, sh.ovf);
-                        sh.n = g.n; sh.want = want; sh.rb_min = rb_min;
-                    }
-                    if (!sh.ok) return ~(size_t)0;
-                    out = a;
-                    out.hash_size = 8u * sh.chunks * sh.regions; out.vis_rb = 0; out.vis_chunks = sh.chunks; out.ovf_size = sh.ovf;
-                    out.vis_regions = sh.regions; out.vis_magic = (uint32_t)(0x100000000ull / sh.regions);
-                    return search_lds_bytes(out, std_heap);
-                };
-                SearchArgs b16 = a, bb = a;
-                size_t lds16 = ~(size_t)0, ldsb = ~(size_t)0;
-                uint32_t rb = 0, slots = 0;
-                if (!forceb && visited16_shape(g.n, want_visit, rb_min, rb, slots)) {
-                    b16.hash_size = slots; b16.vis_rb = rb;
-                    lds16 = search_lds_bytes(b16, std_heap);
+// One launch of the call: tier 0 over all its queries, tier t > 0 over the queries that outgrew tier t - 1's tables
+// (listed in c.cur's twin), on tables 2^t times the size.  Queues the launch's report behind it.
+void DeviceIndex::launch_tier(SearchCall& c)
+{
+    SearchArgs& a = c.a;
+    const int tier = c.tier, ef = c.ef;
+    const uint32_t flags = c.flags;
+    const bool no_alloc = c.no_alloc;
+    hipStream_t stream = reinterpret_cast<hipStream_t>(c.stream);
+    const bool q8 = (flags & HNSW_AMD_ROWS_Q8) != 0, u8 = (flags & HNSW_AMD_ROWS_U8) != 0;
+    const bool ip = (flags & HNSW_AMD_METRIC_IP) != 0, scalar = (flags & HNSW_AMD_DIST_SCALAR) != 0;
+    const int max_lds = dev_max_lds, num_cus = dev_num_cus;
+    const uint32_t rb_min = (uint32_t)tune.rb_min;
+    const uint32_t spill_tables = tune.spill_tables >= 0 ? std::min<uint32_t>(kSpillTables, (uint32_t)tune.spill_tables) : kSpillTables;
+    const bool force_bulk = tune.want_bulk >= 0;
+
+    const uint32_t want_visit = c.want_visit0 << tier;
+    a.spill_pool = nullptr; a.spill_tables = 0; a.spill_slots = 0; a.vis_regions = 0; a.vis_magic = 0;
+    a.hash_size = hash32_slots(want_visit); a.vis_rb = 0xFFFFFFFFu; a.vis_chunks = 0; a.ovf_size = 0;
+    a.cap_c = std::max(((c.want_c0 << tier) + 31u) & ~31u, ((uint32_t)ef + 33u) & ~31u);      // W is sorted in C's space at the end
+    const bool std_heap = (flags & HNSW_AMD_W_STD_HEAP) != 0 || ef > 256;
+    if (!std_heap && a.cap_w > a.cap_c) throw std::logic_error("search: W does not fit the space it borrows for the final sort");
+    size_t lds = search_lds_bytes(a, std_heap);
+    const int wr = std_heap ? 0 : (ef <= 64 ? 1 : (ef <= 128 ? 2 : 4));
+    // wide rows in a batch that leaves most of the chip idle: more loads in flight per query
+    // (its 240 registers and two wavefronts per query leave a CU four queries: batches of up to four per CU)
+    const bool deep_rows = g.d > 256 && (uint64_t)a.nq_launch <= 4ull * (uint64_t)num_cus && !tune.no_deep_rows;
+    const SearchKernel kern_p = pick_kernel(scalar, wr, u8 ? 1 : (q8 ? 2 : 0), false, ip, g.d, tune.generic_rows, deep_rows);     // probing forms
+    const SearchKernel kern_b = pick_kernel(scalar, wr, u8 ? 1 : (q8 ? 2 : 0), true, ip, g.d, tune.generic_rows);      // bucket form
+    // LDS a query may use without lowering residency: the float-row kernels need 110-118 VGPRs, i.e. 4 waves per
+    // SIMD = 16 one-wave workgroups per CU (the byte-row kernels could run 24, measured no faster than 16), and a
+    // batch of fewer than 16 queries per CU needs even fewer slots (bounded, so that clearing the tables stays cheap).
+    const uint32_t per_cu = std::min<uint32_t>(16u, (a.nq_launch + (uint32_t)num_cus - 1u) / (uint32_t)num_cus);
+    size_t budget = std::min<size_t>(kLdsPerCu / per_cu, 40960);
+    if (tune.lds_budget >= 0) budget = std::min<size_t>(budget, (size_t)tune.lds_budget);
+    // (the deep form runs two wavefronts per query, which talk through a mailbox behind the query's tables)
+    constexpr size_t kMailBytes = 1024;
+    const bool deep_kernel = deep_rows && !scalar && !u8 && !q8 && !ip;
+    if (deep_kernel && budget > 4 * kMailBytes) budget -= kMailBytes;
+    {
+        // 16-bit visited slots where they let a CU hold more queries: the probing form (large regions) or the
+        // bucket form (small regions read whole, nearly full, plus an overflow table), whichever needs less LDS.
+        const bool force16 = tune.visited16, forceb = tune.visitedb;
+        if (!tune.visited32 && (force16 || forceb || lds > budget)) {
+            auto occupancy = [&](size_t bytes, bool bucket = false) {
+                if (bytes > 65536) return (int)(kLdsPerCu / bytes);
+                // (asked of the runtime once per kernel and size: the call costs microseconds, a batch a few hundred)
+                const void* fn = reinterpret_cast<const void*>(bucket ? kern_b : kern_p);
+                for (const OccupancyNote& o : occupancy_notes) if (o.kernel == fn && o.bytes == bytes) return o.blocks;
+                int occ = 0;
+                HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, 64, bytes));
+                if (occupancy_notes.size() >= 64) occupancy_notes.clear();
+                occupancy_notes.push_back({fn, bytes, occ});
+                return occ;
+            };
+            auto bucket_args = [&](uint32_t want, BucketShape& sh, SearchArgs& out) -> size_t {
+                if (sh.n != g.n || sh.want != want || sh.rb_min != rb_min) {
+                    sh.ok = bucket_shape(g.n, want, rb_min, sh.regions, sh.chunks, sh.ovf);
+                    sh.n = g.n; sh.want = want; sh.rb_min = rb_min;
                 }
-                if (!force16) {
-                    ldsb = bucket_args(want_visit, shape_full, bb);
-                    // Tables for the bulk of the queries and spill tables for the rest, where that lets a CU hold more
-                    // queries (first tier only; HNSW_AMD_NO_SPILL: never)
-                    const bool spill_ok = tier == 0 && want_bulk0 > 0 && !getenv("HNSW_AMD_NO_SPILL") && (d_spill != nullptr || !no_alloc);
-                    if (spill_ok && ldsb != ~(size_t)0 && ldsb <= lds16) {
-                        SearchArgs bs = a;
-                        const size_t ldss = bucket_args(want_bulk0, shape_bulk, bs);
-                        if (ldss != ~(size_t)0 && (force_bulk || occupancy(ldss, true) > occupancy(ldsb, true))) {
-                            if (!d_spill) HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_spill), (size_t)kSpillTables * kSpillSlots * 4));
-                            bs.spill_pool = d_spill; bs.spill_tables = spill_tables; bs.spill_slots = kSpillSlots;
-                            bb = bs; ldsb = ldss;
-                        }
+                if (!sh.ok) return ~(size_t)0;
+                out = a;
+                out.hash_size = 8u * sh.chunks * sh.regions; out.vis_rb = 0; out.vis_chunks = sh.chunks; out.ovf_size = sh.ovf;
+                out.vis_regions = sh.regions; out.vis_magic = (uint32_t)(0x100000000ull / sh.regions);
+                return search_lds_bytes(out, std_heap);
+            };
+            SearchArgs b16 = a, bb = a;
+            size_t lds16 = ~(size_t)0, ldsb = ~(size_t)0;
+            uint32_t rb = 0, slots = 0;
+            if (!forceb && visited16_shape(g.n, want_visit, rb_min, rb, slots)) {
+                b16.hash_size = slots; b16.vis_rb = rb;
+                lds16 = search_lds_bytes(b16, std_heap);
+            }
+            if (!force16) {
+                ldsb = bucket_args(want_visit, shape_full, bb);
+                // Tables for the bulk of the queries and spill tables for the rest, where that lets a CU hold more
+                // queries (first tier only; HNSW_AMD_NO_SPILL: never)
+                const bool spill_ok = tier == 0 && c.want_bulk0 > 0 && !tune.no_spill && (c.d_spill != nullptr || !no_alloc);
+                if (spill_ok && ldsb != ~(size_t)0 && ldsb <= lds16) {
+                    SearchArgs bs = a;
+                    const size_t ldss = bucket_args(c.want_bulk0, shape_bulk, bs);
+                    if (ldss != ~(size_t)0 && (force_bulk || occupancy(ldss, true) > occupancy(ldsb, true))) {
+                        if (!c.d_spill) HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&c.d_spill), (size_t)kSpillTables * kSpillSlots * 4));
+                        bs.spill_pool = c.d_spill; bs.spill_tables = spill_tables; bs.spill_slots = kSpillSlots;
+                        bb = bs; ldsb = ldss;
                     }
-                }
-                const bool use_b = ldsb < lds16;
-                const size_t ldsn = use_b ? ldsb : lds16;
-                if (ldsn != ~(size_t)0) {
-                    const int occ32 = occupancy(lds), occn = occupancy(ldsn, use_b);
-                    // (beyond 16 queries per CU the cheaper 32-bit probe wins: measured on the byte-row kernel, 16 -> 20)
-                    if (force16 || forceb || (occn > occ32 && occ32 < 16)) { a = use_b ? bb : b16; lds = ldsn; }
                 }
             }
+            const bool use_b = ldsb < lds16;
+            const size_t ldsn = use_b ? ldsb : lds16;
+            if (ldsn != ~(size_t)0) {
+                const int occ32 = occupancy(lds), occn = occupancy(ldsn, use_b);
+                // (beyond 16 queries per CU the cheaper 32-bit probe wins: measured on the byte-row kernel, 16 -> 20)
+                if (force16 || forceb || (occn > occ32 && occ32 < 16)) { a = use_b ? bb : b16; lds = ldsn; }
+            }
         }
-        // What the estimate leaves of the budget goes to the tables (a quarter to the heap): a lower load makes the
-        // visited probes shorter, and the occasional far-reaching query is spared its re-run.
-        if (a.vis_rb == 0xFFFFFFFFu && lds < budget) {
-            const uint32_t slack = (uint32_t)(budget - lds);
-            const uint32_t more_c = (slack / 4u / 8u) & ~31u;
-            a.cap_c += more_c;
-            a.hash_size += ((slack - more_c * 8u) / 4u) & ~63u;
-            lds = search_lds_bytes(a, std_heap);
-        }
-        if (lds > (size_t)max_lds) {
-            throw std::length_error("search: " + std::to_string(a.nq_launch) +
-                                    " queries outgrew the largest on-chip scratch configuration (ef too large for LDS?)");
-        }
-        const SearchKernel kern = a.vis_chunks ? kern_b : kern_p;
-        const bool two_waves = deep_kernel && !a.vis_chunks;
-        const unsigned block_threads = two_waves ? 128u : 64u;
-        a.mail_off = 0;
-        if (two_waves) {
-            a.mail_off = (uint32_t)(lds / 4);
-            lds += kMailBytes;
-            if (lds > (size_t)max_lds) throw std::length_error("search: the query's scratch and the two-wavefront mailbox do not fit the LDS");
-        }
-        a.fail_count = cur; a.fail_list = cur + kFailHeader;
-        HIP_CHECK(hipMemsetAsync(cur, 0, 4 * kFailHeader, stream));
-        h_fail[kFailHeader - 1] = 0xFFFFFFFFu;               // (the report replaces it with the header's zero)
-        if (lds > 32768)
-            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        if (const char* pad = getenv("HNSW_AMD_LDS_PAD")) lds += (size_t)atoi(pad);      // occupancy experiments
-        if (getenv("HNSW_AMD_VERBOSE")) {
-            int nb = 0;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), (int)block_threads, lds);
-            char form[96];
-            if (a.vis_rb == 0xFFFFFFFFu) snprintf(form, sizeof form, "%u slots of 32 bits", a.hash_size);
-            else if (a.vis_chunks) snprintf(form, sizeof form, "%u regions x %u slots of 16 bits + %u overflow%s", a.vis_regions, 8u * a.vis_chunks, a.ovf_size,
-                                            a.spill_tables ? " + spill tables" : "");
-            else snprintf(form, sizeof form, "%u slots of 16 bits in %u regions", a.hash_size, 1u << a.vis_rb);
-            fprintf(stderr, "[hnsw_amd] search launch: %u queries, ef=%d, tier %d (visited: %s for %u ids, C %u), LDS %zu B, resident queries per CU %d%s\n",
-                    a.nq_launch, ef, tier, form, want_visit, a.cap_c, lds, nb, two_waves ? ", two wavefronts per query" : "");
-        }
+    }
+    // What the estimate leaves of the budget goes to the tables (a quarter to the heap): a lower load makes the
+    // visited probes shorter, and the occasional far-reaching query is spared its re-run.
+    if (a.vis_rb == 0xFFFFFFFFu && lds < budget) {
+        const uint32_t slack = (uint32_t)(budget - lds);
+        const uint32_t more_c = (slack / 4u / 8u) & ~31u;
+        a.cap_c += more_c;
+        a.hash_size += ((slack - more_c * 8u) / 4u) & ~63u;
+        lds = search_lds_bytes(a, std_heap);
+    }
+    if (lds > (size_t)max_lds) {
+        throw std::length_error("search: " + std::to_string(a.nq_launch) +
+                                " queries outgrew the largest on-chip scratch configuration (ef too large for LDS?)");
+    }
+    const SearchKernel kern = a.vis_chunks ? kern_b : kern_p;
+    const bool two_waves = deep_kernel && !a.vis_chunks;
+    const unsigned block_threads = two_waves ? 128u : 64u;
+    a.mail_off = 0;
+    if (two_waves) {
+        a.mail_off = (uint32_t)(lds / 4);
+        lds += kMailBytes;
+        if (lds > (size_t)max_lds) throw std::length_error("search: the query's scratch and the two-wavefront mailbox do not fit the LDS");
+    }
+    a.fail_count = c.cur; a.fail_list = c.cur + kFailHeader;
+    HIP_CHECK(hipMemsetAsync(c.cur, 0, 4 * kFailHeader, stream));
+    // The report's words are preset to all ones on the host; the device's copy holds zero in the last word (cleared
+    // with the rest of the header, never written by the kernel) and counts that cannot be all ones in the others.
+    for (uint32_t w = 0; w < kFailHeader; w++) c.h_report[w] = 0xFFFFFFFFu;
+    set_max_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
+    lds += (size_t)tune.lds_pad;
+    if (tune.verbose) {
+        int nb = 0;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), (int)block_threads, lds);
+        char form[96];
+        if (a.vis_rb == 0xFFFFFFFFu) snprintf(form, sizeof form, "%u slots of 32 bits", a.hash_size);
+        else if (a.vis_chunks) snprintf(form, sizeof form, "%u regions x %u slots of 16 bits + %u overflow%s", a.vis_regions, 8u * a.vis_chunks, a.ovf_size,
+                                        a.spill_tables ? " + spill tables" : "");
+        else snprintf(form, sizeof form, "%u slots of 16 bits in %u regions", a.hash_size, 1u << a.vis_rb);
+        fprintf(stderr, "[hnsw_amd] search launch: %u queries, ef=%d, tier %d (visited: %s for %u ids, C %u), LDS %zu B, resident queries per CU %d%s\n",
+                a.nq_launch, ef, tier, form, want_visit, a.cap_c, lds, nb, two_waves ? ", two wavefronts per query" : "");
+    }
+    c.timed = tune.verbose && !no_alloc;
+    if (c.timed) {
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
-        const bool timed = getenv("HNSW_AMD_VERBOSE") != nullptr && sync_and_retry && !no_alloc;
-        if (timed) { HIP_CHECK(hipEventCreate(&ev0)); HIP_CHECK(hipEventCreate(&ev1)); HIP_CHECK(hipEventRecord(ev0, stream)); }
-        hipLaunchKernelGGL(kern, dim3(a.nq_launch), dim3(block_threads), lds, stream, a);
-        HIP_CHECK(hipGetLastError());
-        if (tier == 0) { last_kernel = reinterpret_cast<const void*>(kern); last_lds = (uint32_t)lds; last_block = block_threads; last_form = a.vis_rb == 0xFFFFFFFFu ? 0 : (a.vis_chunks ? 2 : 1); }
-        if (timed) {
-            HIP_CHECK(hipEventRecord(ev1, stream));
-            HIP_CHECK(hipEventSynchronize(ev1));
-            float ms = 0.0f;
-            HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1));
-            fprintf(stderr, "[hnsw_amd] search kernel: %.4f ms for %u queries\n", ms, a.nq_launch);
-            (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
-        }
-        if (!sync_and_retry) return 0;
-        if (copy_back) HIP_CHECK(hipMemcpyAsync(copy_back->dst, copy_back->src, copy_back->bytes, hipMemcpyDeviceToHost, stream));
-        // The launch's report travels to a pinned host buffer whose last word the host has set to all ones and the device
-        // copy holds as zero (cleared with the rest of the header before the launch, never written by the kernel), and
-        // the host waits by watching that word: no stream synchronisation (the caller's stream is often the legacy default stream, whose
-        // synchronisation also covers whatever other threads of the process keep adding to it or to streams it
-        // synchronises with), no event, nothing to wake up — measured 20 us per call less than an event wait, which is
-        // 4 % of a 10 000-query batch at ef=20.  The stream is queried now and then so that an error ends the wait.
-        HIP_CHECK(hipMemcpyAsync(h_fail, cur, 4 * kFailHeader, hipMemcpyDeviceToHost, stream));
-        volatile uint32_t* report = h_fail;
-        for (uint32_t spins = 0; report[kFailHeader - 1] != 0u; spins++) {
-            __builtin_ia32_pause();
-            if ((spins & 0xFFFu) == 0xFFFu) {
-                const hipError_t q = hipStreamQuery(stream);
-                if (q == hipSuccess) {
-                    // everything queued has run: the report is in memory (or never will be)
-                    if (report[kFailHeader - 1] != 0u) HIP_CHECK(hipStreamSynchronize(stream));
-                    if (report[kFailHeader - 1] != 0u) throw std::runtime_error("HIP: the launch's report did not arrive");
-                    break;
-                }
-                if (q != hipErrorNotReady) HIP_CHECK(q);
+        HIP_CHECK(hipEventCreate(&ev0)); HIP_CHECK(hipEventCreate(&ev1));
+        c.ev0 = ev0; c.ev1 = ev1;
+        HIP_CHECK(hipEventRecord(ev0, stream));
+    }
+    hipLaunchKernelGGL(kern, dim3(a.nq_launch), dim3(block_threads), lds, stream, a);
+    HIP_CHECK(hipGetLastError());
+    if (tier == 0) { last_kernel = reinterpret_cast<const void*>(kern); last_lds = (uint32_t)lds; last_block = block_threads; last_form = a.vis_rb == 0xFFFFFFFFu ? 0 : (a.vis_chunks ? 2 : 1); }
+    if (c.timed) HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(c.ev1), stream));
+    if (c.has_copy_back) HIP_CHECK(hipMemcpyAsync(c.copy_back.dst, c.copy_back.src, c.copy_back.bytes, hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipMemcpyAsync(c.h_report, c.cur, 4 * kFailHeader, hipMemcpyDeviceToHost, stream));
+    c.launched = true;
+}
+
+// The launch's report travels to a pinned host buffer, and the host waits by watching it: no stream synchronisation (the
+// caller's stream is often the legacy default stream, whose synchronisation also covers whatever other threads of the
+// process keep adding to it or to streams it synchronises with), no event, nothing to wake up — measured 20 us per call
+// less than an event wait, which is 4 % of a 10 000-query batch at ef=20.  The wait spins for the length of an ordinary
+// batch, then yields the core between looks, then sleeps between them; the stream is queried now and then so that an
+// error ends the wait.  Every word read afterwards is itself waited for (all were preset to a value the device never
+// sends), so nothing depends on the order in which the words of the copy land.
+void DeviceIndex::wait_report(SearchCall& c)
+{
+    hipStream_t stream = reinterpret_cast<hipStream_t>(c.stream);
+    volatile uint32_t* report = c.h_report;
+    auto arrived = [&]() {
+        if (report[kFailHeader - 1] != 0u) return false;
+        for (uint32_t w = 0; w < 6; w++) if (report[w] == 0xFFFFFFFFu) return false;
+        return true;
+    };
+    for (uint32_t spins = 0; !arrived(); spins++) {
+        if (spins < (1u << 16)) __builtin_ia32_pause();                 // (a few milliseconds)
+        else if (spins < (1u << 16) + 4096u) std::this_thread::yield();
+        else std::this_thread::sleep_for(std::chrono::microseconds(50));
+        if ((spins & 0xFFFu) == 0xFFFu || spins > (1u << 16) + 4096u) {
+            const hipError_t q = hipStreamQuery(stream);
+            if (q == hipSuccess) {
+                // everything queued has run: the report is in memory (or never will be)
+                if (!arrived()) HIP_CHECK(hipStreamSynchronize(stream));
+                if (!arrived()) throw std::runtime_error("HIP: the launch's report did not arrive");
+                break;
             }
+            if (q != hipErrorNotReady) HIP_CHECK(q);
         }
-        std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+}
+
+uint32_t DeviceIndex::finish(SearchCall* cp)
+{
+    if (!cp || !cp->busy) throw std::logic_error("search: finish without a call in flight");
+    SearchCall& c = *cp;
+    struct Release {                       // whatever happens, the call's slot is free afterwards
+        SearchCall& c;
+        ~Release() {
+            if (c.ev0) (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(c.ev0));
+            if (c.ev1) (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(c.ev1));
+            c.ev0 = c.ev1 = nullptr;
+            c.busy = false;
+        }
+    } release{c};
+    if (c.nq == 0) return 0;
+    HIP_CHECK(hipSetDevice(device));
+    SearchArgs& a = c.a;
+    for (;;) {
+        wait_report(c);
+        if (c.timed) {
+            float ms = 0.0f;
+            HIP_CHECK(hipEventSynchronize(reinterpret_cast<hipEvent_t>(c.ev1)));
+            HIP_CHECK(hipEventElapsedTime(&ms, reinterpret_cast<hipEvent_t>(c.ev0), reinterpret_cast<hipEvent_t>(c.ev1)));
+            fprintf(stderr, "[hnsw_amd] search kernel: %.4f ms for %u queries\n", ms, a.nq_launch);
+            (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(c.ev0)); (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(c.ev1));
+            c.ev0 = c.ev1 = nullptr;
+        }
 #ifdef HNSW_CHECKS
         {
             uint32_t bad = 0;
@@ -2064,36 +2189,59 @@ uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32
             if (bad) throw std::logic_error("search (checking build): " + std::to_string(bad) + " invariant violations in the visited set");
         }
 #endif
-        const uint32_t nfail = h_fail[0];
-        seen_visit = std::max(seen_visit, h_fail[1]);
-        seen_c = std::max(seen_c, h_fail[2]);
-        seen_sum16 += h_fail[4]; seen_done += h_fail[5];
-        if (getenv("HNSW_AMD_VERBOSE"))
+        const uint32_t* r = c.h_report;
+        const uint32_t nfail = r[0];
+        c.seen_visit = std::max(c.seen_visit, r[1]);
+        c.seen_c = std::max(c.seen_c, r[2]);
+        c.seen_sum16 += r[4]; c.seen_done += r[5];
+        if (tune.verbose)
             fprintf(stderr, "[hnsw_amd]   %u of %u queries outgrew their scratch, %u used a spill table; largest visited set %u, room asked of C %u\n",
-                    nfail, a.nq_launch, std::min(h_fail[3], a.spill_tables), h_fail[1], h_fail[2]);
+                    nfail, a.nq_launch, std::min(r[3], a.spill_tables), r[1], r[2]);
         if (nfail == 0) break;
-        retried += nfail;
-        a.qmap = cur + kFailHeader; a.nq_launch = nfail;
-        std::swap(cur, other);
+        c.retried += nfail;
+        a.qmap = c.cur + kFailHeader; a.nq_launch = nfail;
+        std::swap(c.cur, c.other);
+        c.tier++;
+        launch_tier(c);
     }
     // remember what this batch needed (the maxima are those of the queries that finished, i.e. of all of them)
-    const uint32_t seen_mean = seen_done ? (uint32_t)(seen_sum16 * 16u / seen_done) : 0u;
-    if (seen_visit == 0 && learn_ef != ef) {
+    const int ef = c.ef;
+    const uint32_t nq = c.nq;
+    const uint32_t seen_mean = c.seen_done ? (uint32_t)(c.seen_sum16 * 16u / c.seen_done) : 0u;
+    if (c.flags != learn_flags) {
+        // (another kind of search was begun since this one: what it learnt goes to the notes)
+        bool put = false;
+        for (LearnNote& o : learn_notes) if (o.flags == c.flags && o.ef == ef) {
+            o.visit = std::max(o.visit, c.seen_visit); o.c = std::max(o.c, c.seen_c); put = true;
+        }
+        if (!put && c.seen_visit) {
+            const LearnNote note = {c.flags, ef, c.seen_visit, c.seen_c, nq >= 64 ? seen_mean : 0u, 1u};
+            if (learn_notes.size() < 16) learn_notes.push_back(note);
+            else learn_notes[learn_notes_next++ % 16u] = note;
+        }
+    } else if (c.seen_visit == 0 && learn_ef != ef) {
         // (a diagnostic build of the kernel reports nothing)
     } else if (learn_ef == ef) {
         // Grows at once, shrinks slowly (one far-reaching query should not cost residency for ever).  A launch that
         // was told the known maxima reports only what went beyond them.
         if (a.known_visit) {
-            learn_visit = std::max(learn_visit, seen_visit); learn_c = std::max(learn_c, seen_c);
-        } else if (seen_visit) {
-            learn_visit = std::max(seen_visit, (uint32_t)(((uint64_t)learn_visit * 15u + seen_visit) / 16u));
-            learn_c = std::max(seen_c, (uint32_t)(((uint64_t)learn_c * 15u + seen_c) / 16u));
+            learn_visit = std::max(learn_visit, c.seen_visit); learn_c = std::max(learn_c, c.seen_c);
+        } else if (c.seen_visit) {
+            learn_visit = std::max(c.seen_visit, (uint32_t)(((uint64_t)learn_visit * 15u + c.seen_visit) / 16u));
+            learn_c = std::max(c.seen_c, (uint32_t)(((uint64_t)learn_c * 15u + c.seen_c) / 16u));
         }
         if (nq >= 64) learn_mean = (uint32_t)(((uint64_t)learn_mean * 3u + seen_mean) / 4u);
     } else if (nq >= 64 || learn_ef == 0) {
-        learn_ef = ef; learn_visit = seen_visit; learn_c = seen_c; learn_mean = nq >= 64 ? seen_mean : 0u;
+        learn_ef = ef; learn_visit = c.seen_visit; learn_c = c.seen_c; learn_mean = nq >= 64 ? seen_mean : 0u;
     }
-    return retried;
+    return c.retried;
+}
+
+uint32_t DeviceIndex::search(const float* d_queries, uint32_t nq, int ef, uint32_t out_k, uint32_t flags, uint32_t* d_ids,
+                             float* d_dist, uint32_t* d_count, hnsw_amd_query_stats* d_stats, void* stream_v,
+                             bool no_alloc, const CopyBack* copy_back)
+{
+    return finish(begin(d_queries, nq, ef, out_k, flags, d_ids, d_dist, d_count, d_stats, stream_v, no_alloc, copy_back));
 }
 
 }  // namespace hnsw_amd

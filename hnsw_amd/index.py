@@ -121,6 +121,25 @@ class HNSW:
                                                                    d_count or None, d_stats or None, stream or None, C.byref(retried)))
         return retried.value
 
+    def search_batch_device_begin(self, d_queries: int, nq: int, ef: int, out_k: int, d_ids: int, d_dist: int, d_count: int = 0,
+                                  d_stats: int = 0, stream: int = 0, flags: int | None = None):
+        """Launches the batch and returns a handle at once; search_batch_device_finish(handle) waits for it (and re-runs
+        what outgrew its scratch).  Up to four calls may be in flight on one index."""
+        call = C.c_void_p()
+        capi.check(capi.lib().hnsw_amd_search_batch_device_begin(self._h, d_queries, nq, ef, out_k,
+                                                                 self.flags if flags is None else flags, d_ids, d_dist,
+                                                                 d_count or None, d_stats or None, stream or None, C.byref(call)))
+        return call
+
+    def search_batch_device_finish(self, call) -> int:
+        retried = C.c_uint32(0)
+        capi.check(capi.lib().hnsw_amd_search_batch_device_finish(self._h, call, C.byref(retried)))
+        return retried.value
+
+    def reload_env(self) -> None:
+        """The library reads its diagnostic environment switches when the index is copied to the GPU; read them again."""
+        capi.check(capi.lib().hnsw_amd_reload_env(self._h))
+
     def gather_ceiling(self, n_waves: int, rows_per_wave: int, lds_bytes_per_wave: int, stream: int = 0):
         """(ms, bytes) of one launch of the row-gather probe on this index's vector table (see include/hnsw_amd.h)."""
         ms, nbytes = C.c_float(0), C.c_uint64(0)

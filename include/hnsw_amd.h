@@ -26,6 +26,7 @@ extern "C" {
 #endif
 
 typedef struct hnsw_amd_index hnsw_amd_index;
+typedef struct hnsw_amd_search_call hnsw_amd_search_call;   /* a batched search between its begin and its finish */
 
 enum {
     HNSW_AMD_OK = 0,
@@ -121,11 +122,13 @@ int hnsw_amd_insert(hnsw_amd_index* h, const float* q);
 int hnsw_amd_insert_batch(hnsw_amd_index* h, const float* rows, uint32_t n, int threads);
 /* The same loop with the construction searches of layer-0-only vectors (19 in 20) run on the GPU: HNSW::insert's
  * searchLayer(q, efConstruction) (src/hnsw.cpp:246-262) is the query path, so the batched search kernel supplies the
- * candidate lists of a sub-batch at a time on the graph as it stands (sub-batches of at most an eighth of the linked
- * nodes, 32768 rows at most), and the host threads run selectNeighbors and the linking (src/hnsw.cpp:263-323,
+ * candidate lists of a sub-batch at a time on the graph as it stands (a sub-batch is a sixteenth of the nodes linked
+ * so far, 16384 rows at most; while the graph is small, a quarter of it up to 1024 rows), and the host threads run selectNeighbors and the linking (src/hnsw.cpp:263-323,
  * 1078-1126) as in the concurrent build.  Vectors of one sub-batch do not see each other: a valid HNSW graph of the
  * same rule, not the reference's exact adjacency.  Needs threads > 1 and n >= 2048 (else: hnsw_amd_insert_batch).
- * `device`: the GPU that searches (and holds the index afterwards). */
+ * `device`: the GPU that searches (and holds the index afterwards).  If the build fails half way (a HIP error in a
+ * candidate search) the index is left unusable: every later insert or search returns HNSW_AMD_E_ARG until
+ * hnsw_amd_init / hnsw_amd_load_graph / hnsw_amd_import_flat starts it over. */
 int hnsw_amd_insert_batch_assisted(hnsw_amd_index* h, const float* rows, uint32_t n, int threads, int device);
 /* Construction option with no counterpart in the reference: key the candidate heap of the searches that insert()
  * runs by the float distance instead of the reference's int32 truncation (src/hnsw.cpp:727,767).  Off by default
@@ -155,6 +158,22 @@ int hnsw_amd_search_batch(hnsw_amd_index* h, const float* queries, uint32_t nq, 
 int hnsw_amd_search_batch_device(hnsw_amd_index* h, const float* d_queries, uint32_t nq, int ef, uint32_t out_k,
                                  uint32_t flags, uint32_t* d_out_ids, float* d_out_dist, uint32_t* d_out_count,
                                  hnsw_amd_query_stats* d_stats, void* stream, uint32_t* retried);
+
+/* No counterpart in the reference (whose driver runs one blocking query at a time).  hnsw_amd_search_batch_device in
+ * two halves, so that a caller can keep several batches in flight on one index and use the time a batch takes on the
+ * GPU: begin sizes the batch's on-chip scratch from what earlier batches needed, launches it on `stream` and returns
+ * at once with a handle in *call; finish waits for that launch, re-runs the queries that outgrew their scratch on
+ * larger tables (on the same stream, waiting for each such launch) and only then are all output rows final;
+ * *retried (host, may be NULL) as above.  Every successful begin needs exactly one finish, which also releases the
+ * handle, whatever it returns.  At most 4 calls may be in flight per index (HNSW_AMD_E_ARG beyond); they may use
+ * different streams and be finished in any order; each has its own scratch lists and spill tables, so calls that
+ * overlap on the GPU do not interfere.  Between a begin and its finish the index must not be modified, re-uploaded or
+ * destroyed, and the output buffers of calls in flight must be distinct.  begin and finish themselves are ordinary
+ * calls on the index: one thread at a time. */
+int hnsw_amd_search_batch_device_begin(hnsw_amd_index* h, const float* d_queries, uint32_t nq, int ef, uint32_t out_k,
+                                       uint32_t flags, uint32_t* d_out_ids, float* d_out_dist, uint32_t* d_out_count,
+                                       hnsw_amd_query_stats* d_stats, void* stream, hnsw_amd_search_call** call);
+int hnsw_amd_search_batch_device_finish(hnsw_amd_index* h, hnsw_amd_search_call* call, uint32_t* retried);
 
 /* No counterpart in the reference.  hnsw_amd_search_batch_device for callers that cannot allocate device memory
  * (tight serving loops, harnesses that forbid hipMalloc): same arguments, same results, but the call itself
@@ -213,6 +232,11 @@ int hnsw_amd_bruteforce_knn_device(const float* d_base, uint32_t n, const float*
 int hnsw_amd_merge_topk_device(const float* d_dist, const uint32_t* d_ids, const uint32_t* shard_offset, uint32_t n_shards,
                                uint32_t nq, uint32_t k, uint32_t out_k, uint64_t shard_stride, uint32_t* d_out_ids, float* d_out_dist,
                                void* stream);
+
+/* Development aid, no counterpart in the reference: the library's diagnostic switches (environment variables
+ * HNSW_AMD_VERBOSE, HNSW_AMD_VISITED32, ...; listed where they are read, hnsw_kernels.hip) are read when an index is
+ * copied to its GPU, not in every search call; this reads them again for `h`. */
+int hnsw_amd_reload_env(hnsw_amd_index* h);
 
 /* Public data members of the reference object that callers read (src/hnsw.h:221-236). */
 int hnsw_amd_get_info(hnsw_amd_index* h, int32_t* M, int32_t* Mmax, int32_t* Mmax0, int32_t* efConstruction,

@@ -86,3 +86,27 @@ def test_assisted_build_in_several_calls_and_small_batches():
     oi, od, oc = idx.search(q[:200], 30, threads=8)
     assert np.array_equal(c, oc)
     assert_same_results(ids, dist, oi, od, what="after three assisted calls")
+
+
+def test_assisted_build_after_init_with_other_data_of_the_same_shape():
+    """A handle that is init()ed again with the same row count and dimension holds other rows: the device copy of
+    the first table must not pass for the second one (few rows, so that no layer-raising vector forces a new upload
+    during the second build)."""
+    n, d = 4000, 128
+    first = datagen.make("sift", n, seed=21)
+    second = datagen.make("sift", n, seed=22)
+    q = datagen.make("sift", 200, seed=22, stream=1)
+    h = HNSW(16, 16, 100)
+    h.init(d, n)
+    h.insert_batch(first, threads=16, gpu=True)
+    h.search_batch(q, 30)
+    h.init(d, n)
+    h.insert_batch(second, threads=16, gpu=True)
+    idx = oracle.OracleIndex(h.export_flat(), second)
+    ids, dist, c = h.search_batch(q, 30)
+    oi, od, oc = idx.search(q, 30, threads=8)
+    assert np.array_equal(c, oc)
+    assert_same_results(ids, dist, oi, od, what="second table of the same shape")
+    # and the graph was built on the second table's rows: its vectors find themselves
+    ids, dist, _ = h.search_batch(second[:100], 30, out_k=1)
+    assert (dist[:, 0] == 0).all()

@@ -48,7 +48,8 @@ def test_kernel_matches_oracle_with_counters(name, keys, w):
         ids, dist, cnt, st = h.search_batch(g.queries, ef, flags=dflag | kflag, stats=True)
         oi, od, oc, ost = idx.search(g.queries, ef, dist_mode=g.dist_mode, key_mode=kmode, stats=True)
         assert np.array_equal(cnt, oc)
-        assert_same_results(ids, dist, oi, od, what=f"{name} ef={ef} keys={keys}")
+        # (W_ kept as the reference keeps it: even the members of the last tie group agree)
+        assert_same_results(ids, dist, oi, od, what=f"{name} ef={ef} keys={keys}", last_group_open=(w != "std_heap"))
         for field in st.dtype.names:
             assert np.array_equal(st[field], ost[field]), f"{name} ef={ef}: counter {field} differs"
 
@@ -62,8 +63,11 @@ def test_row_shape_kernels_equal_the_kernel_for_any_row_length(name, monkeypatch
     h.import_flat(g.graph, g.base)
     for ef in (10, 50, 100, 200):
         monkeypatch.delenv("HNSW_AMD_GENERIC_ROWS", raising=False)
+        h.sync_device()
+        h.reload_env()           # (the switches are read when the index goes to the GPU, not per call)
         ids, dist, cnt, st = h.search_batch(g.queries, ef, flags=_flags(g), stats=True)
         monkeypatch.setenv("HNSW_AMD_GENERIC_ROWS", "1")
+        h.reload_env()
         ids2, dist2, cnt2, st2 = h.search_batch(g.queries, ef, flags=_flags(g), stats=True)
         assert np.array_equal(ids, ids2) and np.array_equal(dist, dist2) and np.array_equal(cnt, cnt2)
         for field in st.dtype.names:
@@ -223,6 +227,8 @@ def test_all_forms_of_the_visited_set_give_the_same_search(monkeypatch):
             monkeypatch.delenv("HNSW_AMD_VIS_RB_MIN", raising=False)
         else:
             monkeypatch.setenv("HNSW_AMD_VIS_RB_MIN", str(rb_min))
+        h.sync_device()
+        h.reload_env()           # (the switches are read when the index goes to the GPU, not per call)
         return h.search_batch(q, ef, stats=True)
 
     for ef in (8, 60, 100, 200, 256, 300):

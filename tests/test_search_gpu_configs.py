@@ -73,6 +73,8 @@ def test_scalar_order_at_every_row_shape(d, monkeypatch):
                 monkeypatch.setenv("HNSW_AMD_GENERIC_ROWS", "1")
             else:
                 monkeypatch.delenv("HNSW_AMD_GENERIC_ROWS", raising=False)
+            h.sync_device()
+            h.reload_env()       # (the switches are read when the index goes to the GPU, not per call)
             ids, dist, cnt, st = h.search_batch(q, ef, flags=flags, stats=True)
             assert np.array_equal(cnt, oc)
             assert_same_results(ids, dist, oi, od, what=f"scalar order d={d} ef={ef} generic={generic}")

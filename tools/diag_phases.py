@@ -36,6 +36,7 @@ t = time.time(); h.insert_batch(base, threads=a.threads); print(f"build {time.ti
 h.sync_device(0)
 if a.want_visit:
     os.environ["HNSW_AMD_WANT_VISIT"] = str(a.want_visit)
+    h.reload_env()
 for rep in range(2):
     t = time.time()
     ids, ds, cnt, st = h.search_batch(q, a.ef, out_k=10, stats=True)

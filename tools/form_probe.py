@@ -64,9 +64,11 @@ for ef in [int(x) for x in a.ef.split(",")]:
             os.environ["HNSW_AMD_BULK_FRAC"] = opt
         try:
             os.environ["HNSW_AMD_VERBOSE"] = "1"
+            h.reload_env()
             for _ in range(3):      # discovery, sized from observation, bulk sizing
                 retried = h.search_batch_device(q_t.data_ptr(), nq, ef, 10, ids.data_ptr(), ds.data_ptr(), cnt.data_ptr(), st_t.data_ptr(), stream, flags)
             os.environ.pop("HNSW_AMD_VERBOSE")
+            h.reload_env()
             retried = h.search_batch_device(q_t.data_ptr(), nq, ef, 10, ids.data_ptr(), ds.data_ptr(), cnt.data_ptr(), st_t.data_ptr(), stream, flags)
             torch.cuda.synchronize()
             st = st_t.cpu().numpy().view(np.uint32).reshape(nq, 8).copy().view(capi.STATS_DTYPE).reshape(nq)
