@@ -81,6 +81,7 @@ struct SearchCall {
     uint32_t nq = 0, flags = 0, retried = 0;
     int ef = 0, tier = 0;
     bool no_alloc = false, launched = false, timed = false, has_copy_back = false;
+    bool dot4 = false;                // the current launch reads byte rows through integer dot products
     void* stream = nullptr;
     uint32_t *cur = nullptr, *other = nullptr;        // the list the current launch appends to, and the other one
     uint32_t want_visit0 = 0, want_c0 = 0, want_bulk0 = 0;
@@ -103,6 +104,7 @@ public:
     uint64_t rows_epoch = 0;      // HostIndex::rows_epoch_ of the vector table that was uploaded
     DeviceGraph g{};
     static constexpr int kMaxCallsInFlight = 4;
+    bool dot4_off = false;            // most queries of an earlier batch were not integer-valued: byte rows go through the float arithmetic
     Tunables tune;
     struct OccupancyNote { const void* kernel; size_t bytes; int blocks; };
     std::vector<OccupancyNote> occupancy_notes;   // resident workgroups per CU the runtime reported, by kernel and LDS size
@@ -136,7 +138,7 @@ public:
     void last_launch(uint32_t& lds_bytes, uint32_t& resident_per_cu, uint32_t& visited_form) const;
     const void* last_kernel = nullptr;
     uint32_t last_lds, last_block = 0;
-    int last_form = 0;
+    int last_form = 0, last_wps = 4;
     // Diagnostic: milliseconds of one launch in which n_waves wavefronts each read rows_per_wave random rows of the
     // vector table with the search kernel's loads and distance arithmetic and nothing else; `bytes` = what the
     // search's counters would charge for those rows.  lds_bytes per wavefront sets the residency.

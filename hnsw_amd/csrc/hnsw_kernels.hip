@@ -40,7 +40,8 @@
 // per device (noalloc_scratch_for) and passed as an argument like any other buffer.
 constexpr uint32_t kNoAllocMaxQueries = 65535;
 constexpr uint32_t kFailHeader = 8;      // words before the list: [0] count, [1] largest visited set, [2] most room C was asked for in the
-                                         // launch, [3] spill tables handed out, [4] sum of visited counts / 16 and [5] number of a sample (one in 32) of the queries that finished
+                                         // launch, [3] spill tables handed out, [4] sum of visited counts / 16 and [5] number of a sample (one in 32) of the queries that finished,
+                                         // [6] queries handed back because the integer arithmetic of the byte rows does not apply to them, [7] always zero
 static __device__ __align__(256) uint32_t scratch[2 * (kNoAllocMaxQueries + kFailHeader)];
 
 namespace hnsw_amd {
@@ -506,18 +507,29 @@ __device__ __forceinline__ void issue_item(const float* p, uint32_t nld, float4 
 // of a 96-dim row; the first four of a 128-dim row, whose kernels have less room), so that a distance batch does not
 // wait for them to come out of LDS piece by piece.
 // (Byte rows of 128 dims: all eight pieces, in the byte rows' own order of the query copy; those kernels have the room.)
-template <int NL, int ROWS = 0>
+// RK: 0 = float rows, 1 = byte rows read through the float arithmetic, 2 = byte rows through integer dot products (the
+// lane's 32 bytes of each 128-dim block of the query as packed bytes, plus the query's squared norm).
+template <int NL, int RK = 0>
 struct QRegs {
     // (the scalar-order kernels, NL = 7, read the query from LDS)
-    static constexpr int K = ROWS != 0 ? (NL == 8 ? 8 : 0) : (NL == 6 ? 6 : (NL == 8 ? 4 : 0));
+    static constexpr int K = RK == 2 ? 0 : (RK != 0 ? (NL == 8 ? 8 : 0) : (NL == 6 ? 6 : (NL == 8 ? 4 : 0)));
     float4 q[K ? K : 1];
+    static constexpr int KB = RK == 2 && NL == 8 ? 2 : 0;
+    uint4 qb[KB ? KB : 1];
+    uint32_t qq;
 };
-template <int NL, int ROWS>
-__device__ __forceinline__ void qregs_load(QRegs<NL, ROWS>& qr, const float* qs, int lane)
+// which of the three a kernel's ROWS parameter means (ROWS: 0 float rows, 1 exact byte rows, 2 quantised byte rows,
+// 3 exact byte rows through integer dot products)
+__host__ __device__ constexpr int row_kind(int ROWS) { return ROWS == 0 ? 0 : (ROWS == 3 ? 2 : 1); }
+template <int NL, int RK>
+__device__ __forceinline__ void qregs_load(QRegs<NL, RK>& qr, const float* qs, int lane)
 {
 #pragma unroll
-    for (int t = 0; t < QRegs<NL, ROWS>::K; t++)
-        qr.q[t] = *reinterpret_cast<const float4*>(ROWS != 0 ? qs + 32 * (lane & 3) + 4 * t : qs + 8 * (lane & 3) + 32 * (t >> 1) + 4 * (t & 1));
+    for (int t = 0; t < QRegs<NL, RK>::K; t++)
+        qr.q[t] = *reinterpret_cast<const float4*>(RK != 0 ? qs + 32 * (lane & 3) + 4 * t : qs + 8 * (lane & 3) + 32 * (t >> 1) + 4 * (t & 1));
+#pragma unroll
+    for (int t = 0; t < QRegs<NL, RK>::KB; t++)
+        qr.qb[t] = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(qs) + 32 * (lane & 3) + 16 * t);
 }
 
 // SSE order, lane j of the row's quad: p / qp point at this lane's 8 floats of the item's first line.
@@ -731,20 +743,80 @@ __device__ __forceinline__ void batch_distance_u8(const DistCtx& c, const uint8_
     }
 }
 
+// Byte rows through integer dot products.  When every stored value and every element of the query is an integer in 0..255
+// and the largest possible distance, 255^2 per used dim, stays below 2^24, every partial sum of the reference's four float
+// chains (src/hnsw.h:349-380) is an integer that a float holds exactly: no step of the chain rounds, so the result is the
+// exact integer sum of (q_i - x_i)^2 whatever the order of the additions, and
+//     sum (q - x)^2 = sum q^2 - 2 sum q x + sum x^2
+// computed in integers and converted once has the same bits.  v_dot4_u32_u8 takes four products per instruction: a dword
+// of the row costs two instructions (q.x and x.x) instead of four conversions, four subtractions and four multiply-adds.
+// row[s] points at this lane's 32 bytes of the row's first 128-dim block; the lane's partial sums meet in the quad.
+// `qbytes`: the query as packed bytes in LDS, in the byte rows' order.
+template <int NL = 0>
+__device__ __forceinline__ void batch_distance_dot4(const DistCtx& c, const uint8_t* const (&row)[2], const bool (&act)[2],
+                                                    float (&out)[2], int lane, const QRegs<NL, 2>& qr)
+{
+    static_assert(NL == 0 || NL == 8, "byte rows: the kernel for any row length, or the one for 128 dims");
+    const uint32_t ni = NL ? 1u : c.nitems, nf = NL ? 1u : c.nfull, tl = NL ? 0u : c.tail_loads;
+    const uint8_t* qbytes = reinterpret_cast<const uint8_t*>(c.qs) + 32 * (lane & 3);
+    int32_t acc[2] = {0, 0};
+    uint4 A[2], B[2];
+    const uint32_t total = 2 * ni;
+    auto issue = [&](uint4 (&v)[2], uint32_t i) {
+        const uint32_t s = i >= ni ? 1u : 0u, g = i - s * ni;
+        if (s ? act[1] : act[0]) issue_item_u8((s ? row[1] : row[0]) + g * 128u, v);
+    };
+    auto consume = [&](const uint4 (&v)[2], uint32_t i) {
+        const uint32_t s = i >= ni ? 1u : 0u, g = i - s * ni;
+        if (s ? act[1] : act[0]) {
+            uint32_t qx = 0, xx = 0;
+            uint4 q[2];
+            if constexpr (NL != 0) { q[0] = qr.qb[0]; q[1] = qr.qb[1]; }
+            else { q[0] = *reinterpret_cast<const uint4*>(qbytes + g * 128u); q[1] = *reinterpret_cast<const uint4*>(qbytes + g * 128u + 16); }
+            const uint32_t nw = (NL || g < nf) ? 8u : tl;
+#pragma unroll
+            for (int w = 0; w < 8; w++)
+                if (NL || (uint32_t)w < nw) {
+                    const uint32_t x = u4_get(v[w >> 2], w & 3);
+                    qx = __builtin_amdgcn_udot4(x, u4_get(q[w >> 2], w & 3), qx, false);
+                    xx = __builtin_amdgcn_udot4(x, x, xx, false);
+                }
+            const int32_t t = (int32_t)xx - 2 * (int32_t)qx;
+            if (s) acc[1] += t; else acc[0] += t;
+        }
+    };
+    issue(A, 0);
+    issue(B, 1);
+    for (uint32_t i = 0; i < total; i += 2) {
+        consume(A, i);
+        if (i + 2 < total) issue(A, i + 2);
+        consume(B, i + 1);
+        if (i + 3 < total) issue(B, i + 3);
+    }
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        int t = acc[s];
+        t += __builtin_amdgcn_update_dpp(0, t, 0xB1, 0xF, 0xF, false);     // quad_perm [1,0,3,2]
+        t += __builtin_amdgcn_update_dpp(0, t, 0x4E, 0xF, 0xF, false);     // quad_perm [2,3,0,1]
+        out[s] = (float)(t + (int32_t)qr.qq);
+    }
+}
+
 // Distances to the rows `id[s]` (sub-batch s; act[s]: the lane's row takes part), from the float or the byte table.
 template <bool SCALAR, int ROWS, int NBUF = 2, bool IP = false, int SUB = -1, int NL = 0>
 __device__ __forceinline__ void rows_distance(const DeviceGraph& g, const DistCtx& c, const uint32_t (&id)[RowMap<SCALAR>::kSub],
                                               const bool (&act)[RowMap<SCALAR>::kSub], float (&out)[RowMap<SCALAR>::kSub], int lane,
-                                              const QRegs<NL, (ROWS != 0 ? 1 : 0)>& qr = QRegs<NL, (ROWS != 0 ? 1 : 0)>())
+                                              const QRegs<NL, row_kind(ROWS)>& qr = QRegs<NL, row_kind(ROWS)>())
 {
     typedef RowMap<SCALAR> RM;
     if constexpr (ROWS != 0) {
         static_assert(!SCALAR, "byte rows are read in SSE order only");
-        const uint8_t* const table = ROWS == 1 ? g.vectors_u8 : g.vectors_q8;
+        const uint8_t* const table = ROWS == 2 ? g.vectors_q8 : g.vectors_u8;
         const uint8_t* row[2];
 #pragma unroll
         for (int s = 0; s < 2; s++) row[s] = table + (size_t)id[s] * g.row_stride_u8 + 32u * (lane & 3);
-        batch_distance_u8<NL>(c, row, act, out, lane, qr);
+        if constexpr (ROWS == 3) batch_distance_dot4<NL>(c, row, act, out, lane, qr);
+        else batch_distance_u8<NL>(c, row, act, out, lane, qr);
     } else {
         const float* row[RM::kSub];
 #pragma unroll
@@ -889,8 +961,12 @@ __device__ __forceinline__ uint32_t w_set_replace_max(uint32_t (&wd)[WR], uint32
 // NL: 0 = rows of any length; 8 / 6 = a kernel for rows of exactly 128 / 96 used dims (float rows, SSE order; 8 also for byte
 //     rows), 7 = for the scalar order on rows of 97..112 dims without a fused tail (d = 100), 704 = the deep form for rows of
 //     960 used dims (7 whole items + 4 loads); their distance batches are straight-line code.
-template <bool SCALAR, int WR, int ROWS, bool BUCKET, int NBUF, bool IP, int NL>
-__global__ __launch_bounds__(NBUF == 2 ? 64 : 128) __attribute__((amdgpu_waves_per_eu(NBUF == 2 ? 4 : 1, NBUF == 2 ? 4 : 2))) void hnsw_search_kernel(SearchArgs a)
+// WPS: wavefronts per SIMD the kernel is pinned at (one-wavefront workgroups: four times as many queries per CU).  4 for
+//      all but the kernels that read byte rows through integer dot products, which need half the registers of the others
+//      and also exist pinned at 6 for ef <= 64, where a query's LDS can be small enough for 24 queries per CU.  (A kernel
+//      is pinned because one that may run more wavefronts per SIMD than LDS lets the CU hold fills the SIMDs unevenly.)
+template <bool SCALAR, int WR, int ROWS, bool BUCKET, int NBUF, bool IP, int NL, int WPS = 4>
+__global__ __launch_bounds__(NBUF == 2 ? 64 : 128) __attribute__((amdgpu_waves_per_eu(NBUF == 2 ? WPS : 1, NBUF == 2 ? WPS : 2))) void hnsw_search_kernel(SearchArgs a)
 {
     typedef RowMap<SCALAR> RM;
     typedef BatchLanes<SCALAR> BL;
@@ -963,7 +1039,36 @@ __global__ __launch_bounds__(NBUF == 2 ? 64 : 128) __attribute__((amdgpu_waves_p
     const uint32_t ef = a.ef;
 
     // query into LDS in stored form (zero padded), visited set empty
-    {
+    QRegs<NL, row_kind(ROWS)> qr;
+    if constexpr (ROWS == 3) {
+        // as packed bytes (a.qpad counts dwords of four); a query with an element that is not an integer in 0..255 cannot
+        // take the integer arithmetic: it is handed back like a query that outgrew its scratch (the re-run uses floats)
+        const float* q = a.queries + (size_t)qi * a.g.d;
+        const uint32_t d_used = a.g.d & ~15u;
+        uint8_t* qb = reinterpret_cast<uint8_t*>(qs);
+        bool inexact = false;
+        uint32_t sq = 0;
+        for (uint32_t i = lane; i < 4u * a.qpad; i += 64) {
+            const float v = i < d_used ? q[i] : 0.0f;
+            const uint32_t b = (uint32_t)(v >= 0.0f && v <= 255.0f ? (int)v : 0);
+            inexact = inexact || (float)b != v;
+            sq += b * b;
+            qb[stored_pos_u8(i)] = (uint8_t)b;
+        }
+        for (uint32_t i = lane; i < hash_words; i += 64) hash[i] = kEmpty;
+        if (__ballot(inexact)) {
+            if (lane == 0) {
+                const uint32_t at = atomicAdd(a.fail_count, 1u);
+                a.fail_list[at] = qi;
+                atomicAdd(&a.fail_count[6], 1u);
+                if (a.out_count) a.out_count[qi] = kEmpty;
+            }
+            return;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sq += (uint32_t)__shfl_xor((int)sq, off);
+        qr.qq = rfl(sq);
+    } else {
         const float* q = a.queries + (size_t)qi * a.g.d;
         for (uint32_t i = lane; i < a.qpad; i += 64) {
             float v = i < a.g.d ? q[i] : 0.0f;
@@ -973,7 +1078,6 @@ __global__ __launch_bounds__(NBUF == 2 ? 64 : 128) __attribute__((amdgpu_waves_p
         for (uint32_t i = lane; i < hash_words; i += 64) hash[i] = kEmpty;
     }
     LDS_SYNC();
-    QRegs<NL, (ROWS != 0 ? 1 : 0)> qr;
     qregs_load(qr, qs, lane);
 
     hnsw_amd_query_stats st = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1571,6 +1675,7 @@ void DeviceIndex::upload(const HostIndex& h, int dev)
     (void)noalloc_scratch_for(dev, true);
     tune.read();
     func_lds_.clear();
+    dot4_off = false;
     version = h.version_;
     rows_epoch = h.rows_epoch_;
     learn_flags = 0; learn_ef = 0; learn_visit = 0; learn_c = 0; learn_mean = 0; learn_notes.clear();
@@ -1691,14 +1796,16 @@ void DeviceIndex::last_launch(uint32_t& lds_bytes, uint32_t& resident_per_cu, ui
     int nb = 0;
     if (last_lds <= 65536) HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, last_kernel, (int)last_block, last_lds));
     else nb = (int)(163840 / last_lds);
+    if (last_block == 64 && nb > 4 * last_wps) nb = 4 * last_wps;        // (the kernel is pinned at last_wps wavefronts per SIMD)
     resident_per_cu = (uint32_t)nb;
 }
 
 typedef void (*SearchKernel)(SearchArgs);
 
 template <bool SCALAR, int ROWS, bool BUCKET, int NBUF, bool IP = false, int NL = 0>
-static SearchKernel pick_wr(int wr)
+static SearchKernel pick_wr(int wr, int wps = 4)
 {
+    if constexpr (ROWS == 3) { if (wr == 1 && wps == 6) return hnsw_search_kernel<SCALAR, 1, ROWS, BUCKET, NBUF, IP, NL, 6>; }
     switch (wr) {
         case 0: return hnsw_search_kernel<SCALAR, 0, ROWS, BUCKET, NBUF, IP, NL>;
         case 1: return hnsw_search_kernel<SCALAR, 1, ROWS, BUCKET, NBUF, IP, NL>;
@@ -1708,13 +1815,15 @@ static SearchKernel pick_wr(int wr)
 }
 
 template <bool BUCKET>
-static SearchKernel pick_rows(bool scalar, int wr, int rows, bool ip, int nl)
+static SearchKernel pick_rows(bool scalar, int wr, int rows, bool ip, int nl, int wps)
 {
     if (ip && nl == 8) return pick_wr<false, 0, BUCKET, 2, true, 8>(wr);
     if (ip && nl == 6) return pick_wr<false, 0, BUCKET, 2, true, 6>(wr);
     if (ip) return pick_wr<false, 0, BUCKET, 2, true>(wr);
     if (scalar && nl == 7) return pick_wr<true, 0, BUCKET, 2, false, 7>(wr);
     if (scalar) return pick_wr<true, 0, BUCKET, 2>(wr);
+    if (rows == 3 && nl == 8) return pick_wr<false, 3, BUCKET, 2, false, 8>(wr, wps);
+    if (rows == 3) return pick_wr<false, 3, BUCKET, 2>(wr, wps);
     if (rows == 1 && nl == 8) return pick_wr<false, 1, BUCKET, 2, false, 8>(wr);
     if (rows == 2 && nl == 8) return pick_wr<false, 2, BUCKET, 2, false, 8>(wr);
     if (rows == 1) return pick_wr<false, 1, BUCKET, 2>(wr);
@@ -1725,7 +1834,7 @@ static SearchKernel pick_rows(bool scalar, int wr, int rows, bool ip, int nl)
 }
 
 // deep: the float-row, probing-form kernel with six row pieces in flight and two wavefronts per query (see hnsw_search_kernel)
-static SearchKernel pick_kernel(bool scalar, int wr, int rows, bool bucket, bool ip, uint32_t d, bool generic /* the kernel for any row length */, bool deep = false)
+static SearchKernel pick_kernel(bool scalar, int wr, int rows, bool bucket, bool ip, uint32_t d, bool generic /* the kernel for any row length */, bool deep = false, int wps = 4)
 {
     if (deep && !scalar && rows == 0 && !bucket && !ip) {
         // (960 used dims = seven whole 128-dim items and one of four loads: the shape of the configuration this form exists for)
@@ -1733,7 +1842,7 @@ static SearchKernel pick_kernel(bool scalar, int wr, int rows, bool bucket, bool
         return pick_wr<false, 0, false, 6>(wr);
     }
     const int nl = generic ? 0 : row_shape_loads(d, scalar);
-    return bucket ? pick_rows<true>(scalar, wr, rows, ip, nl) : pick_rows<false>(scalar, wr, rows, ip, nl);
+    return bucket ? pick_rows<true>(scalar, wr, rows, ip, nl, wps) : pick_rows<false>(scalar, wr, rows, ip, nl, wps);
 }
 
 constexpr size_t kLdsPerCu = 163840;     // gfx950: 160 KB
@@ -1905,7 +2014,6 @@ SearchCall* DeviceIndex::begin(const float* d_queries, uint32_t nq, int ef, uint
     const bool ip = (flags & HNSW_AMD_METRIC_IP) != 0;
     if (ip && (u8 || q8 || (flags & HNSW_AMD_DIST_SCALAR)))
         throw std::invalid_argument("search: HNSW_AMD_METRIC_IP goes with float rows and HNSW_AMD_DIST_SSE only");
-    a.qpad = (u8 || q8) ? ((g.d + 127u) & ~127u) : ((g.d + 63u) & ~63u);
     a.out_ids = d_ids; a.out_dist = d_dist; a.out_count = d_count; a.stats = d_stats;
 
     if (dev_max_lds == 0) {
@@ -1985,99 +2093,118 @@ void DeviceIndex::launch_tier(SearchCall& c)
     const uint32_t spill_tables = tune.spill_tables >= 0 ? std::min<uint32_t>(kSpillTables, (uint32_t)tune.spill_tables) : kSpillTables;
     const bool force_bulk = tune.want_bulk >= 0;
 
+    // Exact byte rows through integer dot products where that is provably the same arithmetic: at most 255^2 per used
+    // dim must stay below 2^24 (d <= 256 + 15).  The first launch only: a query that is not integer-valued is handed back
+    // and re-run with the float arithmetic; an index whose queries mostly are not stops trying.
+    const bool dot4 = u8 && tier == 0 && !tune.no_dot4 && !dot4_off && (uint64_t)(g.d & ~15u) * 65025ull < (1ull << 24);
+    c.dot4 = dot4;
+    a.qpad = dot4 ? ((g.d + 127u) & ~127u) / 4u : ((u8 || q8) ? ((g.d + 127u) & ~127u) : ((g.d + 63u) & ~63u));
     const uint32_t want_visit = c.want_visit0 << tier;
-    a.spill_pool = nullptr; a.spill_tables = 0; a.spill_slots = 0; a.vis_regions = 0; a.vis_magic = 0;
-    a.hash_size = hash32_slots(want_visit); a.vis_rb = 0xFFFFFFFFu; a.vis_chunks = 0; a.ovf_size = 0;
-    a.cap_c = std::max(((c.want_c0 << tier) + 31u) & ~31u, ((uint32_t)ef + 33u) & ~31u);      // W is sorted in C's space at the end
     const bool std_heap = (flags & HNSW_AMD_W_STD_HEAP) != 0 || ef > 256;
-    if (!std_heap && a.cap_w > a.cap_c) throw std::logic_error("search: W does not fit the space it borrows for the final sort");
-    size_t lds = search_lds_bytes(a, std_heap);
     const int wr = std_heap ? 0 : (ef <= 64 ? 1 : (ef <= 128 ? 2 : 4));
-    // wide rows in a batch that leaves most of the chip idle: more loads in flight per query
-    // (its 240 registers and two wavefronts per query leave a CU four queries: batches of up to four per CU)
-    const bool deep_rows = g.d > 256 && (uint64_t)a.nq_launch <= 4ull * (uint64_t)num_cus && !tune.no_deep_rows;
-    const SearchKernel kern_p = pick_kernel(scalar, wr, u8 ? 1 : (q8 ? 2 : 0), false, ip, g.d, tune.generic_rows, deep_rows);     // probing forms
-    const SearchKernel kern_b = pick_kernel(scalar, wr, u8 ? 1 : (q8 ? 2 : 0), true, ip, g.d, tune.generic_rows);      // bucket form
-    // LDS a query may use without lowering residency: the float-row kernels need 110-118 VGPRs, i.e. 4 waves per
-    // SIMD = 16 one-wave workgroups per CU (the byte-row kernels could run 24, measured no faster than 16), and a
-    // batch of fewer than 16 queries per CU needs even fewer slots (bounded, so that clearing the tables stays cheap).
-    const uint32_t per_cu = std::min<uint32_t>(16u, (a.nq_launch + (uint32_t)num_cus - 1u) / (uint32_t)num_cus);
-    size_t budget = std::min<size_t>(kLdsPerCu / per_cu, 40960);
-    if (tune.lds_budget >= 0) budget = std::min<size_t>(budget, (size_t)tune.lds_budget);
-    // (the deep form runs two wavefronts per query, which talk through a mailbox behind the query's tables)
+    const int rows_kind = dot4 ? 3 : (u8 ? 1 : (q8 ? 2 : 0));
     constexpr size_t kMailBytes = 1024;
-    const bool deep_kernel = deep_rows && !scalar && !u8 && !q8 && !ip;
-    if (deep_kernel && budget > 4 * kMailBytes) budget -= kMailBytes;
-    {
-        // 16-bit visited slots where they let a CU hold more queries: the probing form (large regions) or the
-        // bucket form (small regions read whole, nearly full, plus an overflow table), whichever needs less LDS.
-        const bool force16 = tune.visited16, forceb = tune.visitedb;
-        if (!tune.visited32 && (force16 || forceb || lds > budget)) {
-            auto occupancy = [&](size_t bytes, bool bucket = false) {
-                if (bytes > 65536) return (int)(kLdsPerCu / bytes);
-                // (asked of the runtime once per kernel and size: the call costs microseconds, a batch a few hundred)
-                const void* fn = reinterpret_cast<const void*>(bucket ? kern_b : kern_p);
-                for (const OccupancyNote& o : occupancy_notes) if (o.kernel == fn && o.bytes == bytes) return o.blocks;
-                int occ = 0;
-                HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, 64, bytes));
-                if (occupancy_notes.size() >= 64) occupancy_notes.clear();
-                occupancy_notes.push_back({fn, bytes, occ});
-                return occ;
-            };
-            auto bucket_args = [&](uint32_t want, BucketShape& sh, SearchArgs& out) -> size_t {
-                if (sh.n != g.n || sh.want != want || sh.rb_min != rb_min) {
-                    sh.ok = bucket_shape(g.n, want, rb_min, sh.regions, sh.chunks, sh.ovf);
-                    sh.n = g.n; sh.want = want; sh.rb_min = rb_min;
+    SearchKernel kern_p = nullptr, kern_b = nullptr;
+    bool deep_rows = false, deep_kernel = false;
+    size_t lds = 0;
+    const SearchArgs a_in = a;
+    // Wavefronts per SIMD of the kernel: 6 (24 queries per CU) where such a kernel exists (integer dot products, ef <= 64)
+    // and the scratch of a query then fits a 24th of the LDS, else 4 (16 per CU).
+    int wps = (rows_kind == 3 && wr == 1 && (uint64_t)a.nq_launch >= 16ull * (uint64_t)num_cus && tune.lds_budget < 0) ? 6 : 4;
+    for (;; wps = 4) {
+        a = a_in;
+        a.spill_pool = nullptr; a.spill_tables = 0; a.spill_slots = 0; a.vis_regions = 0; a.vis_magic = 0;
+        a.hash_size = hash32_slots(want_visit); a.vis_rb = 0xFFFFFFFFu; a.vis_chunks = 0; a.ovf_size = 0;
+        a.cap_c = std::max(((c.want_c0 << tier) + 31u) & ~31u, ((uint32_t)ef + 33u) & ~31u);      // W is sorted in C's space at the end
+        if (!std_heap && a.cap_w > a.cap_c) throw std::logic_error("search: W does not fit the space it borrows for the final sort");
+        lds = search_lds_bytes(a, std_heap);
+        // wide rows in a batch that leaves most of the chip idle: more loads in flight per query
+        // (its 240 registers and two wavefronts per query leave a CU four queries: batches of up to four per CU)
+        deep_rows = g.d > 256 && (uint64_t)a.nq_launch <= 4ull * (uint64_t)num_cus && !tune.no_deep_rows;
+        kern_p = pick_kernel(scalar, wr, rows_kind, false, ip, g.d, tune.generic_rows, deep_rows, wps);     // probing forms
+        kern_b = pick_kernel(scalar, wr, rows_kind, true, ip, g.d, tune.generic_rows, false, wps);      // bucket form
+        // LDS a query may use without lowering residency: the float-row kernels need 110-118 VGPRs, i.e. 4 waves per
+        // SIMD = 16 one-wave workgroups per CU (the byte-row kernels could run 24, measured no faster than 16), and a
+        // batch of fewer than 16 queries per CU needs even fewer slots (bounded, so that clearing the tables stays cheap).
+        const uint32_t res_cap = 4u * (uint32_t)wps;
+        const uint32_t per_cu = std::min<uint32_t>(res_cap, (a.nq_launch + (uint32_t)num_cus - 1u) / (uint32_t)num_cus);
+        size_t budget = std::min<size_t>(kLdsPerCu / per_cu, 40960);
+        if (tune.lds_budget >= 0) budget = std::min<size_t>(budget, (size_t)tune.lds_budget);
+        // (the deep form runs two wavefronts per query, which talk through a mailbox behind the query's tables)
+        deep_kernel = deep_rows && !scalar && !u8 && !q8 && !ip;
+        if (deep_kernel && budget > 4 * kMailBytes) budget -= kMailBytes;
+        {
+            // 16-bit visited slots where they let a CU hold more queries: the probing form (large regions) or the
+            // bucket form (small regions read whole, nearly full, plus an overflow table), whichever needs less LDS.
+            const bool force16 = tune.visited16, forceb = tune.visitedb;
+            if (!tune.visited32 && (force16 || forceb || lds > budget)) {
+                auto occupancy = [&](size_t bytes, bool bucket = false) {
+                    if (bytes > 65536) return (int)(kLdsPerCu / bytes);
+                    // (asked of the runtime once per kernel and size: the call costs microseconds, a batch a few hundred)
+                    const void* fn = reinterpret_cast<const void*>(bucket ? kern_b : kern_p);
+                    for (const OccupancyNote& o : occupancy_notes) if (o.kernel == fn && o.bytes == bytes) return o.blocks;
+                    int occ = 0;
+                    HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, 64, bytes));
+                    if (occupancy_notes.size() >= 64) occupancy_notes.clear();
+                    occupancy_notes.push_back({fn, bytes, occ});
+                    return occ;
+                };
+                auto bucket_args = [&](uint32_t want, BucketShape& sh, SearchArgs& out) -> size_t {
+                    if (sh.n != g.n || sh.want != want || sh.rb_min != rb_min) {
+                        sh.ok = bucket_shape(g.n, want, rb_min, sh.regions, sh.chunks, sh.ovf);
+                        sh.n = g.n; sh.want = want; sh.rb_min = rb_min;
+                    }
+                    if (!sh.ok) return ~(size_t)0;
+                    out = a;
+                    out.hash_size = 8u * sh.chunks * sh.regions; out.vis_rb = 0; out.vis_chunks = sh.chunks; out.ovf_size = sh.ovf;
+                    out.vis_regions = sh.regions; out.vis_magic = (uint32_t)(0x100000000ull / sh.regions);
+                    return search_lds_bytes(out, std_heap);
+                };
+                SearchArgs b16 = a, bb = a;
+                size_t lds16 = ~(size_t)0, ldsb = ~(size_t)0;
+                uint32_t rb = 0, slots = 0;
+                if (!forceb && visited16_shape(g.n, want_visit, rb_min, rb, slots)) {
+                    b16.hash_size = slots; b16.vis_rb = rb;
+                    lds16 = search_lds_bytes(b16, std_heap);
                 }
-                if (!sh.ok) return ~(size_t)0;
-                out = a;
-                out.hash_size = 8u * sh.chunks * sh.regions; out.vis_rb = 0; out.vis_chunks = sh.chunks; out.ovf_size = sh.ovf;
-                out.vis_regions = sh.regions; out.vis_magic = (uint32_t)(0x100000000ull / sh.regions);
-                return search_lds_bytes(out, std_heap);
-            };
-            SearchArgs b16 = a, bb = a;
-            size_t lds16 = ~(size_t)0, ldsb = ~(size_t)0;
-            uint32_t rb = 0, slots = 0;
-            if (!forceb && visited16_shape(g.n, want_visit, rb_min, rb, slots)) {
-                b16.hash_size = slots; b16.vis_rb = rb;
-                lds16 = search_lds_bytes(b16, std_heap);
-            }
-            if (!force16) {
-                ldsb = bucket_args(want_visit, shape_full, bb);
-                // Tables for the bulk of the queries and spill tables for the rest, where that lets a CU hold more
-                // queries (first tier only; HNSW_AMD_NO_SPILL: never)
-                const bool spill_ok = tier == 0 && c.want_bulk0 > 0 && !tune.no_spill && (c.d_spill != nullptr || !no_alloc);
-                if (spill_ok && ldsb != ~(size_t)0 && ldsb <= lds16) {
-                    SearchArgs bs = a;
-                    const size_t ldss = bucket_args(c.want_bulk0, shape_bulk, bs);
-                    if (ldss != ~(size_t)0 && (force_bulk || occupancy(ldss, true) > occupancy(ldsb, true))) {
-                        if (!c.d_spill) HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&c.d_spill), (size_t)kSpillTables * kSpillSlots * 4));
-                        bs.spill_pool = c.d_spill; bs.spill_tables = spill_tables; bs.spill_slots = kSpillSlots;
-                        bb = bs; ldsb = ldss;
+                if (!force16) {
+                    ldsb = bucket_args(want_visit, shape_full, bb);
+                    // Tables for the bulk of the queries and spill tables for the rest, where that lets a CU hold more
+                    // queries (first tier only; HNSW_AMD_NO_SPILL: never)
+                    const bool spill_ok = tier == 0 && c.want_bulk0 > 0 && !tune.no_spill && (c.d_spill != nullptr || !no_alloc);
+                    if (spill_ok && ldsb != ~(size_t)0 && ldsb <= lds16) {
+                        SearchArgs bs = a;
+                        const size_t ldss = bucket_args(c.want_bulk0, shape_bulk, bs);
+                        if (ldss != ~(size_t)0 && (force_bulk || occupancy(ldss, true) > occupancy(ldsb, true))) {
+                            if (!c.d_spill) HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&c.d_spill), (size_t)kSpillTables * kSpillSlots * 4));
+                            bs.spill_pool = c.d_spill; bs.spill_tables = spill_tables; bs.spill_slots = kSpillSlots;
+                            bb = bs; ldsb = ldss;
+                        }
                     }
                 }
-            }
-            const bool use_b = ldsb < lds16;
-            const size_t ldsn = use_b ? ldsb : lds16;
-            if (ldsn != ~(size_t)0) {
-                const int occ32 = occupancy(lds), occn = occupancy(ldsn, use_b);
-                // (beyond 16 queries per CU the cheaper 32-bit probe wins: measured on the byte-row kernel, 16 -> 20)
-                if (force16 || forceb || (occn > occ32 && occ32 < 16)) { a = use_b ? bb : b16; lds = ldsn; }
+                const bool use_b = ldsb < lds16;
+                const size_t ldsn = use_b ? ldsb : lds16;
+                if (ldsn != ~(size_t)0) {
+                    const int occ32 = occupancy(lds), occn = occupancy(ldsn, use_b);
+                    // (beyond 16 queries per CU the cheaper 32-bit probe wins: measured on the byte-row kernel, 16 -> 20)
+                    if (force16 || forceb || (occn > occ32 && occ32 < (int)res_cap)) { a = use_b ? bb : b16; lds = ldsn; }
+                }
             }
         }
-    }
-    // What the estimate leaves of the budget goes to the tables (a quarter to the heap): a lower load makes the
-    // visited probes shorter, and the occasional far-reaching query is spared its re-run.
-    if (a.vis_rb == 0xFFFFFFFFu && lds < budget) {
-        const uint32_t slack = (uint32_t)(budget - lds);
-        const uint32_t more_c = (slack / 4u / 8u) & ~31u;
-        a.cap_c += more_c;
-        a.hash_size += ((slack - more_c * 8u) / 4u) & ~63u;
-        lds = search_lds_bytes(a, std_heap);
-    }
-    if (lds > (size_t)max_lds) {
-        throw std::length_error("search: " + std::to_string(a.nq_launch) +
-                                " queries outgrew the largest on-chip scratch configuration (ef too large for LDS?)");
+        // What the estimate leaves of the budget goes to the tables (a quarter to the heap): a lower load makes the
+        // visited probes shorter, and the occasional far-reaching query is spared its re-run.
+        if (a.vis_rb == 0xFFFFFFFFu && lds < budget) {
+            const uint32_t slack = (uint32_t)(budget - lds);
+            const uint32_t more_c = (slack / 4u / 8u) & ~31u;
+            a.cap_c += more_c;
+            a.hash_size += ((slack - more_c * 8u) / 4u) & ~63u;
+            lds = search_lds_bytes(a, std_heap);
+        }
+        if (lds > (size_t)max_lds) {
+            throw std::length_error("search: " + std::to_string(a.nq_launch) +
+                                    " queries outgrew the largest on-chip scratch configuration (ef too large for LDS?)");
+        }
+        if (wps == 4 || lds <= kLdsPerCu / (4u * (size_t)wps)) break;
     }
     const SearchKernel kern = a.vis_chunks ? kern_b : kern_p;
     const bool two_waves = deep_kernel && !a.vis_chunks;
@@ -2115,7 +2242,7 @@ void DeviceIndex::launch_tier(SearchCall& c)
     }
     hipLaunchKernelGGL(kern, dim3(a.nq_launch), dim3(block_threads), lds, stream, a);
     HIP_CHECK(hipGetLastError());
-    if (tier == 0) { last_kernel = reinterpret_cast<const void*>(kern); last_lds = (uint32_t)lds; last_block = block_threads; last_form = a.vis_rb == 0xFFFFFFFFu ? 0 : (a.vis_chunks ? 2 : 1); }
+    if (tier == 0) { last_kernel = reinterpret_cast<const void*>(kern); last_lds = (uint32_t)lds; last_block = block_threads; last_wps = wps; last_form = a.vis_rb == 0xFFFFFFFFu ? 0 : (a.vis_chunks ? 2 : 1); }
     if (c.timed) HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(c.ev1), stream));
     if (c.has_copy_back) HIP_CHECK(hipMemcpyAsync(c.copy_back.dst, c.copy_back.src, c.copy_back.bytes, hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipMemcpyAsync(c.h_report, c.cur, 4 * kFailHeader, hipMemcpyDeviceToHost, stream));
@@ -2135,7 +2262,7 @@ void DeviceIndex::wait_report(SearchCall& c)
     volatile uint32_t* report = c.h_report;
     auto arrived = [&]() {
         if (report[kFailHeader - 1] != 0u) return false;
-        for (uint32_t w = 0; w < 6; w++) if (report[w] == 0xFFFFFFFFu) return false;
+        for (uint32_t w = 0; w + 1 < kFailHeader; w++) if (report[w] == 0xFFFFFFFFu) return false;
         return true;
     };
     for (uint32_t spins = 0; !arrived(); spins++) {
@@ -2197,6 +2324,7 @@ uint32_t DeviceIndex::finish(SearchCall* cp)
         if (tune.verbose)
             fprintf(stderr, "[hnsw_amd]   %u of %u queries outgrew their scratch, %u used a spill table; largest visited set %u, room asked of C %u\n",
                     nfail, a.nq_launch, std::min(r[3], a.spill_tables), r[1], r[2]);
+        if (c.dot4 && c.tier == 0 && r[6] > c.nq / 2u) dot4_off = true;
         if (nfail == 0) break;
         c.retried += nfail;
         a.qmap = c.cur + kFailHeader; a.nq_launch = nfail;

@@ -85,3 +85,72 @@ def test_quantised_rows_search_then_exact_rescoring(kind, n, ef):
     gt = oracle.bruteforce(base[:, :used], q[:, :used], k, threads=8)
     r_f, r_q = recall_at_k(ids_f[:, :k], gt, k), recall_at_k(ids_q[:, :k], gt, k)
     assert r_q >= r_f - 0.03, (r_f, r_q)
+
+
+@pytest.mark.parametrize("d,extra", [(128, 0), (128, capi.W_STD_HEAP), (200, 0), (48, capi.KEYS_FLOAT), (272, 0)])
+def test_integer_dot_products_equal_the_float_arithmetic(d, extra, monkeypatch):
+    """Integer-valued rows and queries with 255^2 * d below 2^24: no step of the reference's float chains rounds, so the
+    byte rows may be read through packed integer dot products; HNSW_AMD_NO_DOT4 keeps the float arithmetic.  Same ids,
+    same distance bits, same counters, and nothing is handed back for a re-run.  d = 272 is past the bound
+    (272 * 255^2 > 2^24): the float arithmetic is used whatever the switch says."""
+    import torch
+    n, nq = 30000, 700
+    base = datagen.integer_vectors(n, d, seed=31)
+    q = datagen.integer_vectors(nq, d, seed=31, stream=1)
+    h = HNSW(16, 16, 100)
+    h.init(d, n)
+    h.insert_batch(base, threads=16)
+    h.sync_device(0)
+    q_t = torch.from_numpy(q).cuda()
+    flags = capi.DIST_SSE | capi.ROWS_U8 | extra
+    for ef in (10, 50, 64, 100, 200):
+        res = {}
+        for mode in ("dot4", "float"):
+            if mode == "float":
+                monkeypatch.setenv("HNSW_AMD_NO_DOT4", "1")
+            else:
+                monkeypatch.delenv("HNSW_AMD_NO_DOT4", raising=False)
+            h.reload_env()
+            ids = torch.empty((nq, ef), dtype=torch.int32, device="cuda")
+            ds = torch.empty((nq, ef), dtype=torch.float32, device="cuda")
+            cnt = torch.empty((nq,), dtype=torch.int32, device="cuda")
+            st = torch.empty((nq, 8), dtype=torch.int32, device="cuda")
+            retried = h.search_batch_device(q_t.data_ptr(), nq, ef, ef, ids.data_ptr(), ds.data_ptr(), cnt.data_ptr(), st.data_ptr(), 0, flags)
+            torch.cuda.synchronize()
+            res[mode] = (ids.cpu().numpy(), ds.cpu().numpy().view(np.uint32), cnt.cpu().numpy(), st.cpu().numpy(), retried)
+        for x, y, what in zip(res["dot4"][:4], res["float"][:4], ("ids", "distances", "counts", "counters")):
+            assert np.array_equal(x, y), f"d={d} ef={ef}: {what} differ"
+        assert res["dot4"][4] == 0
+    # and against the float rows
+    a = h.search_batch(q, 50, flags=capi.DIST_SSE | extra)
+    b = h.search_batch(q, 50, flags=flags)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+
+
+def test_queries_that_are_not_integer_valued_take_the_float_arithmetic():
+    """A query with a fractional (or out-of-range) element cannot use the integer dot products: the kernel hands it back
+    and the call re-runs it with the float arithmetic on the same byte rows.  Results equal the float-row search's;
+    exactly the affected queries are re-run."""
+    import torch
+    n, nq, ef = 30000, 600, 50
+    base = datagen.make("sift", n, seed=33)
+    q = datagen.make("sift", nq, seed=33, stream=1)
+    odd = np.arange(nq) % 7 == 3
+    q[odd, 5] += np.float32(0.5)
+    q[np.arange(nq) % 50 == 1, 100] = np.float32(300.0)
+    odd |= np.arange(nq) % 50 == 1
+    h = HNSW(16, 16, 100)
+    h.init(128, n)
+    h.insert_batch(base, threads=16)
+    h.sync_device(0)
+    a = h.search_batch(q, ef, flags=capi.DIST_SSE, stats=True)
+    q_t = torch.from_numpy(q).cuda()
+    ids = torch.empty((nq, ef), dtype=torch.int32, device="cuda")
+    ds = torch.empty((nq, ef), dtype=torch.float32, device="cuda")
+    cnt = torch.empty((nq,), dtype=torch.int32, device="cuda")
+    for _ in range(2):
+        retried = h.search_batch_device(q_t.data_ptr(), nq, ef, ef, ids.data_ptr(), ds.data_ptr(), cnt.data_ptr(), 0, 0, capi.DIST_SSE | capi.ROWS_U8)
+        torch.cuda.synchronize()
+        assert retried == int(odd.sum())
+        assert np.array_equal(ids.cpu().numpy().view(np.uint32), a[0]) and np.array_equal(ds.cpu().numpy().view(np.uint32), a[1].view(np.uint32))
+        assert np.array_equal(cnt.cpu().numpy().view(np.uint32), a[2])

@@ -94,10 +94,13 @@ def test_noalloc_without_a_spill_pool_equals_a_spilling_run(monkeypatch):
     q_t = torch.from_numpy(datagen.make("deep", 400, seed=6, stream=1)).cuda()
     flags = capi.DIST_SSE | capi.KEYS_INT32
     res = {}
+    built = HNSW(16, 16, 100)
+    built.init(96, len(base))
+    built.insert_batch(base, threads=16)
+    graph = built.export_flat()
     for which in ("noalloc", "alloc"):
-        h = HNSW(16, 16, 100)                       # a fresh index each: no pool left behind by the other entry point
-        h.init(96, len(base))
-        h.insert_batch(base, threads=16)
+        h = HNSW(16, 16, 100)                       # a fresh index each (same graph): no pool left behind by the other entry point
+        h.import_flat(graph, base)
         h.sync_device(0)
         fn = h.search_batch_device_noalloc if which == "noalloc" else h.search_batch_device
         res[which] = [_run(h, fn, q_t, ef, 10, flags) for ef in (30, 30)]
