@@ -22,6 +22,7 @@ struct DeviceGraph {
     uint32_t row_stride_u8;     // d rounded up to a multiple of 128
     const uint8_t* vectors_q8;  // same shape: byte = clamp(round((v - q8_lo) * q8_inv_step), 0, 255); nullptr until asked for
     float q8_lo, q8_inv_step;
+    float max_row_norm;         // an upper bound of the Euclidean length of every row
     const uint32_t* adj0;       // n x deg0, 0xFFFFFFFF padded (the live entries are a prefix)
     const uint32_t* up_off;     // nlayers+1
     const uint32_t* up_down;    // U
@@ -43,6 +44,8 @@ struct SearchArgs {
     uint32_t* spill_pool;     // bucket form: spill tables in device memory for queries that outgrow the overflow table
     uint32_t spill_tables, spill_slots;   // how many, and 32-bit slots each (0 tables: such queries are re-run instead)
     uint32_t qpad;            // floats of the query copy in LDS (multiple of 64)
+    uint32_t c_words;         // dwords per entry of the candidate heap: 2, or 1 (key and node_order packed)
+    uint32_t q_overlay;       // 1: the query's copy is dead once the kernel's registers hold it, and W / C / visited start at its place
     uint32_t* out_ids;        // nq x out_k
     float* out_dist;          // nq x out_k
     uint32_t* out_count;      // nq or nullptr
@@ -82,6 +85,7 @@ struct SearchCall {
     int ef = 0, tier = 0;
     bool no_alloc = false, launched = false, timed = false, has_copy_back = false;
     bool dot4 = false;                // the current launch reads byte rows through integer dot products
+    bool packc = false;               // the current launch keeps candidate-heap entries of four bytes
     void* stream = nullptr;
     uint32_t *cur = nullptr, *other = nullptr;        // the list the current launch appends to, and the other one
     uint32_t want_visit0 = 0, want_c0 = 0, want_bulk0 = 0;
@@ -104,6 +108,7 @@ public:
     uint64_t rows_epoch = 0;      // HostIndex::rows_epoch_ of the vector table that was uploaded
     DeviceGraph g{};
     static constexpr int kMaxCallsInFlight = 4;
+    bool pack_off = false;            // most queries of an earlier batch could not promise small candidate keys: eight-byte entries
     bool dot4_off = false;            // most queries of an earlier batch were not integer-valued: byte rows go through the float arithmetic
     Tunables tune;
     struct OccupancyNote { const void* kernel; size_t bytes; int blocks; };

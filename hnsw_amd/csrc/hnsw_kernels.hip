@@ -23,10 +23,12 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <atomic>
 #include <chrono>
 #include <mutex>
 #include <thread>
+#include <type_traits>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -116,6 +118,14 @@ struct WOrder {   // comp(a,b) = a.dist < b.dist
 struct COrder {   // comp(a,b) = a.key > b.key
     static __device__ __forceinline__ bool before(uint2 a, uint2 b) { return (int32_t)a.x > (int32_t)b.x; }
 };
+// Candidate-heap entries of four bytes: key in the top byte, node_order in the other three (an index of fewer than 2^24
+// rows whose keys provably stay below 256; the launcher decides, see DeviceIndex::launch_tier).  Same order, same heap
+// steps; half the LDS.
+struct COrderPacked {
+    static __device__ __forceinline__ bool before(uint32_t a, uint32_t b) { return (a >> 24) > (b >> 24); }
+};
+__device__ __forceinline__ uint2 rfl_entry(uint2 e) { return make_uint2(rfl(e.x), rfl(e.y)); }
+__device__ __forceinline__ uint32_t rfl_entry(uint32_t e) { return rfl(e); }
 
 // Minimum of an unsigned value over the 64 lanes with DPP moves (no LDS round trips):
 // within quads, half rows and rows, then across the four rows; the result is read from lane 63.
@@ -134,8 +144,9 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t x)
 
 
 // push in two halves, so that independent work can be placed between the LDS read and its use
-template <class Ord>
-__device__ __forceinline__ uint2 heap_push_read(const uint2* a, uint32_t n /* size including the new element */, int lane)
+// (E: the entry type, uint2 or the packed uint32_t)
+template <class Ord, class E>
+__device__ __forceinline__ E heap_push_read(const E* a, uint32_t n /* size including the new element */, int lane)
 {
     // every lane reads (the lanes past the chain of ancestors read some valid entry and are masked out of the
     // ballot): no divergent region around the load
@@ -143,8 +154,8 @@ __device__ __forceinline__ uint2 heap_push_read(const uint2* a, uint32_t n /* si
     return a[(anc > 0u ? anc : 1u) - 1u];
 }
 
-template <class Ord>
-__device__ __forceinline__ void heap_push_finish(uint2* a, uint32_t n, uint2 v, uint2 x /* from heap_push_read */, int lane)
+template <class Ord, class E>
+__device__ __forceinline__ void heap_push_finish(E* a, uint32_t n, E v, E x /* from heap_push_read */, int lane)
 {
     const uint32_t depth = 31u - (uint32_t)__clz((int)n);        // levels above index n-1
     const unsigned long long m = __ballot(Ord::before(x, v)) & ((1ull << depth) - 1ull);
@@ -153,18 +164,18 @@ __device__ __forceinline__ void heap_push_finish(uint2* a, uint32_t n, uint2 v, 
     if ((uint32_t)lane <= t) a[(n >> lane) - 1] = (uint32_t)lane < t ? x : v;
 }
 
-template <class Ord>
-__device__ __forceinline__ void heap_push_wave(uint2* a, uint32_t n /* size including the new element */, uint2 v, int lane)
+template <class Ord, class E>
+__device__ __forceinline__ void heap_push_wave(E* a, uint32_t n /* size including the new element */, E v, int lane)
 {
-    heap_push_finish<Ord>(a, n, v, heap_push_read<Ord>(a, n, lane), lane);
+    heap_push_finish<Ord, E>(a, n, v, heap_push_read<Ord, E>(a, n, lane), lane);
 }
 
 // Returns the new root (valid when n > 1).
-template <class Ord>
-__device__ __forceinline__ uint2 heap_pop_wave(uint2* a, uint32_t n /* size before the pop */, int lane)
+template <class Ord, class E>
+__device__ __forceinline__ E heap_pop_wave(E* a, uint32_t n /* size before the pop */, int lane)
 {
     const uint32_t len = n - 1;
-    const uint2 v = a[len];
+    const E v = a[len];
     const uint32_t nint = (len - 1) >> 1;      // nodes with both children inside [0, len)
     const uint32_t nint1 = nint < 256u ? nint : 256u;      // nodes 0..255, the first eight levels, are decided at once
     // Every node of the first eight levels decides at once which child the hole moves to (node 64b + lane in register
@@ -173,20 +184,20 @@ __device__ __forceinline__ uint2 heap_pop_wave(uint2* a, uint32_t n /* size befo
     // the walk never looks at their entries.)
     uint32_t ch0, ch1, ch2 = 0, ch3 = 0;
     {
-        auto children = [&](uint32_t base, uint2& r, uint2& l) {
+        auto children = [&](uint32_t base, E& r, E& l) {
             const uint32_t i = base + (uint32_t)lane, ic = i < nint1 ? i : 0u;
             r = a[2 * ic + 2]; l = a[2 * ic + 1];
         };
-        auto next_of = [&](uint32_t base, const uint2& r, const uint2& l) -> uint32_t {
+        auto next_of = [&](uint32_t base, const E& r, const E& l) -> uint32_t {
             return 2u * (base + (uint32_t)lane) + 2u - (Ord::before(r, l) ? 1u : 0u);
         };
-        uint2 r0, l0, r1, l1;
+        E r0, l0, r1, l1;
         children(0, r0, l0);
         children(64, r1, l1);
         ch0 = next_of(0, r0, l0);
         ch1 = next_of(64, r1, l1);
         if (nint1 > 128) {
-            uint2 r2, l2, r3, l3;
+            E r2, l2, r3, l3;
             children(128, r2, l2);
             children(192, r3, l3);
             ch2 = next_of(128, r2, l2);
@@ -207,33 +218,28 @@ __device__ __forceinline__ uint2 heap_pop_wave(uint2* a, uint32_t n /* size befo
         }
         // a heap of more than 513 entries: the levels below the eighth, one LDS round trip each
         while (idx < nint) {
-            const uint2 r = a[2 * idx + 2], l = a[2 * idx + 1];
-            const bool left = Ord::before(make_uint2(rfl(r.x), rfl(r.y)), make_uint2(rfl(l.x), rfl(l.y)));
+            const E r = a[2 * idx + 2], l = a[2 * idx + 1];
+            const bool left = Ord::before(rfl_entry(r), rfl_entry(l));
             idx = 2 * idx + 2 - (left ? 1u : 0u);
         }
     }
     uint32_t p = idx + 1;                                     // 1-based: a leading 1 followed by one bit per step
     uint32_t d = 31u - (uint32_t)__clz((int)p);               // steps taken
     if ((len & 1u) == 0 && p - 1 == (len - 2) >> 1) { p = 2 * p; d++; }     // a last node with a left child only
-    const uint32_t cur = p - 1;                                              // where the hole ends up
     // lane k owns step k of the path: the element at my_from moves up to my_to
     const uint32_t sh = d - (uint32_t)lane;                                  // meaningful for lane < d
     const uint32_t my_to = (p >> (sh & 31u)) - 1;
     const uint32_t from1 = p >> ((sh - 1) & 31u);          // 1-based; lanes past the path get some index <= p
-    const uint2 x = a[(from1 > 0u ? from1 : 1u) - 1u];     // read by every lane, the ballot is masked instead
+    const E x = a[(from1 > 0u ? from1 : 1u) - 1u];         // read by every lane, the ballot is masked instead
     const unsigned long long cm = __ballot(Ord::before(x, v)) & ((1ull << d) - 1ull);
     uint32_t s = 0;                                       // path elements (from the leaf up) that stay put
     if (d > 0) { s = (uint32_t)__builtin_clzll(~(cm << (64 - d))); if (s > d) s = d; }
     const uint32_t moved = d - s;
     // the first `moved` path elements climb one step; the saved last element lands on step `moved`
-    // (for moved == d that is the end of the path, `cur`)
+    // (for moved == d that is the end of the path)
     if ((uint32_t)lane <= moved) a[my_to] = (uint32_t)lane < moved ? x : v;
-    (void)cur;
     // new root: the first path element if it moved up, else the re-inserted value
-    uint2 root;
-    root.x = moved > 0 ? rfl(x.x) : v.x;
-    root.y = moved > 0 ? rfl(x.y) : v.y;
-    return root;
+    return moved > 0 ? rfl_entry(x) : v;
 }
 
 // Checking build only (-DHNSW_CHECKS, `make -C hnsw_amd/csrc checks`): invariants of the lock-step visited sets are
@@ -518,6 +524,9 @@ struct QRegs {
     uint4 qb[KB ? KB : 1];
     uint32_t qq;
 };
+// Kernels whose QRegs hold every piece of the query (float rows of 96 used dims, SSE order, one wavefront per query): the
+// query's copy in LDS is dead after the registers are loaded, and the tables take its place.
+__host__ __device__ constexpr bool query_overlaid(int NL, int ROWS, bool SCALAR, int NBUF) { return NL == 6 && ROWS == 0 && !SCALAR && NBUF == 2; }
 // which of the three a kernel's ROWS parameter means (ROWS: 0 float rows, 1 exact byte rows, 2 quantised byte rows,
 // 3 exact byte rows through integer dot products)
 __host__ __device__ constexpr int row_kind(int ROWS) { return ROWS == 0 ? 0 : (ROWS == 3 ? 2 : 1); }
@@ -965,11 +974,16 @@ __device__ __forceinline__ uint32_t w_set_replace_max(uint32_t (&wd)[WR], uint32
 //      all but the kernels that read byte rows through integer dot products, which need half the registers of the others
 //      and also exist pinned at 6 for ef <= 64, where a query's LDS can be small enough for 24 queries per CU.  (A kernel
 //      is pinned because one that may run more wavefronts per SIMD than LDS lets the CU hold fills the SIMDs unevenly.)
-template <bool SCALAR, int WR, int ROWS, bool BUCKET, int NBUF, bool IP, int NL, int WPS = 4>
+// PACKC: candidate-heap entries of four bytes (COrderPacked); float rows, int32 keys only.
+template <bool SCALAR, int WR, int ROWS, bool BUCKET, int NBUF, bool IP, int NL, int WPS = 4, bool PACKC = false>
 __global__ __launch_bounds__(NBUF == 2 ? 64 : 128) __attribute__((amdgpu_waves_per_eu(NBUF == 2 ? WPS : 1, NBUF == 2 ? WPS : 2))) void hnsw_search_kernel(SearchArgs a)
 {
     typedef RowMap<SCALAR> RM;
     typedef BatchLanes<SCALAR> BL;
+    typedef typename std::conditional<PACKC, uint32_t, uint2>::type CE;          // an entry of the candidate heap
+    typedef typename std::conditional<PACKC, COrderPacked, COrder>::type COrd;
+    static_assert(!PACKC || (ROWS == 0 && !IP && NBUF == 2 && WR != 0), "packed candidate entries: float rows, squared L2, W in registers");
+    auto c_entry = [](uint32_t key, uint32_t id) -> CE { if constexpr (PACKC) return (key << 24) | id; else return make_uint2(key, id); };
     extern __shared__ __align__(16) uint32_t smem[];
     // The deep form (wide rows, few queries per CU) runs two wavefronts per query: the first walks the graph and takes the
     // rows of sub-batch 0 of every distance batch, the second does nothing but the rows of sub-batch 1 — a row is a serial
@@ -1017,9 +1031,12 @@ __global__ __launch_bounds__(NBUF == 2 ? 64 : 128) __attribute__((amdgpu_waves_p
 
     // LDS: query | W (exact-heap mode only) | C | visited.  The register mode needs W in LDS only for the
     // final sort, when C is dead, so it borrows C's space.
+    // A kernel that keeps the whole query in registers (query_overlaid) lets W / C / visited start where the query's
+    // copy was: that copy is dead once the registers are loaded.
+    constexpr bool kOverlayQ = query_overlaid(NL, ROWS, SCALAR, NBUF);
     float* qs = reinterpret_cast<float*>(smem);
-    uint2* W = reinterpret_cast<uint2*>(smem + a.qpad);
-    uint2* C = W + (WR == 0 ? a.cap_w : 0u);
+    uint2* W = reinterpret_cast<uint2*>(smem + (kOverlayQ ? 0u : a.qpad));
+    CE* C = reinterpret_cast<CE*>(W + (WR == 0 ? a.cap_w : 0u));
     uint32_t* hash = reinterpret_cast<uint32_t*>(C + a.cap_c);
     const uint32_t H = a.hash_size, vis_rb = a.vis_rb;
     const uint32_t primary_words = vis_rb == 0xFFFFFFFFu ? H : H >> 1;
@@ -1070,15 +1087,39 @@ __global__ __launch_bounds__(NBUF == 2 ? 64 : 128) __attribute__((amdgpu_waves_p
         qr.qq = rfl(sq);
     } else {
         const float* q = a.queries + (size_t)qi * a.g.d;
+        float qn = 0.0f;
         for (uint32_t i = lane; i < a.qpad; i += 64) {
             float v = i < a.g.d ? q[i] : 0.0f;
+            if (PACKC) qn = __builtin_fmaf(v, v, qn);
             if (ROWS == 2 && i < a.g.d) v = (v - a.g.q8_lo) * a.g.q8_inv_step;
             qs[ROWS != 0 ? stored_pos_u8(i) : stored_pos(i)] = v;
         }
-        for (uint32_t i = lane; i < hash_words; i += 64) hash[i] = kEmpty;
+        if constexpr (PACKC) {
+            // Keys must stay below 256: no row is farther from the query than (|q| + the longest row)^2.  A query for
+            // which that bound does not hold is handed back (the re-run uses eight-byte entries).
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) qn += __shfl_xor(qn, off);
+            const float reach = __builtin_sqrtf(qn) * 1.001f + a.g.max_row_norm;
+            if (!(reach * reach < 250.0f)) {
+                if (lane == 0) {
+                    const uint32_t at = atomicAdd(a.fail_count, 1u);
+                    a.fail_list[at] = qi;
+                    atomicAdd(&a.fail_count[6], 1u);
+                    if (a.out_count) a.out_count[qi] = kEmpty;
+                }
+                return;
+            }
+        }
+        if (!kOverlayQ) for (uint32_t i = lane; i < hash_words; i += 64) hash[i] = kEmpty;
     }
     LDS_SYNC();
     qregs_load(qr, qs, lane);
+    if constexpr (kOverlayQ) {
+        // (the registers hold the query; its place in LDS now belongs to the tables)
+        LDS_SYNC();
+        for (uint32_t i = lane; i < hash_words; i += 64) hash[i] = kEmpty;
+        LDS_SYNC();
+    }
 
     hnsw_amd_query_stats st = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t fail = 0;
@@ -1174,7 +1215,7 @@ __global__ __launch_bounds__(NBUF == 2 ? 64 : 128) __attribute__((amdgpu_waves_p
         LDS_SYNC();
         if (lane == 0) {
             if (WR == 0) W[0] = make_uint2(__float_as_uint(cur_dist), cur_id);
-            C[0] = make_uint2(float_keys ? __float_as_uint(cur_dist) : (uint32_t)trunc_key(cur_dist), cur_id);
+            C[0] = c_entry(float_keys ? __float_as_uint(cur_dist) : (uint32_t)trunc_key(cur_dist), cur_id);
             visited_insert<BUCKET>(vs, nullptr, cur_id, vis_ovf, used_ovf);
         }
         if (BUCKET) n_ovf = __ballot(lane == 0 && used_ovf) ? 1u : 0u;
@@ -1188,12 +1229,13 @@ __global__ __launch_bounds__(NBUF == 2 ? 64 : 128) __attribute__((amdgpu_waves_p
             uint32_t ckey, cid;
             uint32_t my = kEmpty;                                   // merged form
             {
-                const uint2 c = C[0];
-                ckey = rfl(c.x); cid = rfl(c.y);
+                const CE c = C[0];
+                if constexpr (PACKC) { const uint32_t cw = rfl(c); ckey = cw >> 24; cid = cw & 0xFFFFFFu; }
+                else { ckey = rfl(c.x); cid = rfl(c.y); }
                 // the candidate's neighbour list is requested now and arrives while the heap is repaired
                 if (mrow < a.g.deg0) my = a.g.adj0[(size_t)cid * a.g.deg0 + mrow];
                 if (nC > 1) {
-                    heap_pop_wave<COrder>(C, nC, lane);
+                    heap_pop_wave<COrd, CE>(C, nC, lane);
                 }
                 nC--;
                 LDS_SYNC();
@@ -1275,16 +1317,16 @@ __global__ __launch_bounds__(NBUF == 2 ? 64 : 128) __attribute__((amdgpu_waves_p
                             const uint32_t db = __builtin_amdgcn_readlane(__float_as_uint(dm), j);
                             if (__uint_as_float(db) < f) {
                                 const uint32_t id = __builtin_amdgcn_readlane(my_b, j);
-                                const uint2 ce = make_uint2(__builtin_amdgcn_readlane(keym, j), id);
+                                const CE ce = c_entry(__builtin_amdgcn_readlane(keym, j), id);
                                 nC++;
-                                const uint2 anc = heap_push_read<COrder>(C, nC, lane);      // in flight during the insert into W
+                                const CE anc = heap_push_read<COrd, CE>(C, nC, lane);      // in flight during the insert into W
                                 if constexpr (WR >= 2) {
                                     f = __uint_as_float(w_set_replace_max<(WR > 0 ? WR : 1)>(wd, wi, __float_as_uint(f), db, id, lane));
                                 } else {
                                     w_sorted_insert<(WR > 0 ? WR : 1)>(wd, wi, ef, db, id, lane);
                                     f = __uint_as_float(w_entry_dist<(WR > 0 ? WR : 1)>(wd, ef - 1));
                                 }
-                                heap_push_finish<COrder>(C, nC, ce, anc, lane);
+                                heap_push_finish<COrd, CE>(C, nC, ce, anc, lane);
                                 LDS_SYNC();
                             }
                         }
@@ -1296,11 +1338,11 @@ __global__ __launch_bounds__(NBUF == 2 ? 64 : 128) __attribute__((amdgpu_waves_p
                         const float dist = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(dm), j));
                         if (dist < f || nW < ef) {
                             const uint32_t id = __builtin_amdgcn_readlane(my_b, j);
-                            const uint2 ce = make_uint2(__builtin_amdgcn_readlane(keym, j), id);
+                            const CE ce = c_entry(__builtin_amdgcn_readlane(keym, j), id);
                             const uint2 we = make_uint2(__float_as_uint(dist), id);
                             nC++;
                             if (WR > 0) {
-                                heap_push_wave<COrder>(C, nC, ce, lane);
+                                heap_push_wave<COrd, CE>(C, nC, ce, lane);
                                 if constexpr (WR >= 2) {
                                     if (nW < ef) {
                                         w_set_append<(WR > 0 ? WR : 1)>(wd, wi, nW, we.x, we.y, lane);
@@ -1317,11 +1359,11 @@ __global__ __launch_bounds__(NBUF == 2 ? 64 : 128) __attribute__((amdgpu_waves_p
                                 LDS_SYNC();
                             } else {
                                 nW++;
-                                heap_push_wave<COrder>(C, nC, ce, lane);
-                                heap_push_wave<WOrder>(W, nW, we, lane);
+                                heap_push_wave<COrd, CE>(C, nC, ce, lane);
+                                heap_push_wave<WOrder, uint2>(W, nW, we, lane);
                                 LDS_SYNC();
                                 if (nW > ef) {
-                                    const uint2 root = heap_pop_wave<WOrder>(W, nW, lane);
+                                    const uint2 root = heap_pop_wave<WOrder, uint2>(W, nW, lane);
                                     nW--;
                                     f = __uint_as_float(root.x);
                                     LDS_SYNC();
@@ -1516,6 +1558,20 @@ __global__ void store_rows_kernel(const float* __restrict__ src, float* __restri
     }
 }
 
+// Largest Euclidean length of a row (as the bits of a non-negative float, which order like the float): what the
+// launcher needs to know to promise that candidate keys stay small.
+__global__ void row_norm_max_kernel(const float* __restrict__ src, uint32_t rows, uint32_t d, uint32_t* __restrict__ out_bits)
+{
+    float m = 0.0f;
+    for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (size_t)gridDim.x * blockDim.x) {
+        float sq = 0.0f;
+        for (uint32_t i = 0; i < d; i++) { const float v = src[r * d + i]; sq = __builtin_fmaf(v, v, sq); }
+        const float len = sq == sq ? __builtin_sqrtf(sq) : __builtin_inff();
+        m = len > m ? len : m;
+    }
+    atomicMax(out_bits, __float_as_uint(m * 1.001f));
+}
+
 // The byte table, and whether it is exact: *bad is raised if any value is not an integer in 0..255.
 __global__ void store_rows_u8_kernel(const float* __restrict__ src, uint8_t* __restrict__ dst, uint32_t rows, uint32_t d, uint32_t row_stride_u8,
                                      uint32_t* __restrict__ bad)
@@ -1564,8 +1620,9 @@ static int row_shape_loads(uint32_t d, bool scalar = false)
 
 size_t search_lds_bytes(const SearchArgs& a, bool w_in_lds)
 {
-    size_t dwords = (size_t)a.qpad + (w_in_lds ? 2 * (size_t)a.cap_w : 0) + 2 * (size_t)a.cap_c + (a.vis_rb == 0xFFFFFFFFu ? (size_t)a.hash_size : (size_t)a.hash_size / 2) + (size_t)a.ovf_size;
-    return dwords * 4;
+    size_t dwords = (a.q_overlay ? 0 : (size_t)a.qpad) + (w_in_lds ? 2 * (size_t)a.cap_w : 0) + (size_t)a.c_words * a.cap_c +
+                    (a.vis_rb == 0xFFFFFFFFu ? (size_t)a.hash_size : (size_t)a.hash_size / 2) + (size_t)a.ovf_size;
+    return std::max<size_t>(dwords, a.qpad) * 4;         // (the query is written there first, whatever takes its place later)
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1637,10 +1694,10 @@ void DeviceIndex::upload(const HostIndex& h, int dev)
         uint8_t* du = nullptr;
         HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&du), (size_t)g.n * g.row_stride_u8));
         bufs_[6] = du;
-        uint32_t* d_bad = nullptr;
-        HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_bad), 4));
+        uint32_t* d_bad = nullptr;          // [0] some value is not an integer in 0..255, [1] bits of the largest row length
+        HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_bad), 8));
         bufs_[7] = d_bad;
-        HIP_CHECK(hipMemset(d_bad, 0, 4));
+        HIP_CHECK(hipMemset(d_bad, 0, 8));
         float* tmp = nullptr;
         HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&tmp), (size_t)slab * g.d * sizeof(float)));
         for (uint32_t r0 = 0; r0 < g.n; r0 += slab) {
@@ -1650,6 +1707,7 @@ void DeviceIndex::upload(const HostIndex& h, int dev)
                 hipLaunchKernelGGL(store_rows_kernel, dim3(4096), dim3(256), 0, 0, tmp, dv + (size_t)r0 * g.row_stride, rows, g.d, g.row_stride);
                 hipLaunchKernelGGL(store_rows_u8_kernel, dim3(4096), dim3(256), 0, 0, tmp, du + (size_t)r0 * g.row_stride_u8, rows, g.d,
                                    g.row_stride_u8, d_bad);
+                hipLaunchKernelGGL(row_norm_max_kernel, dim3(1024), dim3(256), 0, 0, tmp, rows, g.d, d_bad + 1);
                 e = hipGetLastError();
             }
             if (e == hipSuccess) e = hipDeviceSynchronize();
@@ -1657,8 +1715,10 @@ void DeviceIndex::upload(const HostIndex& h, int dev)
         }
         HIP_CHECK(hipFree(tmp));
         g.vectors = dv;
-        uint32_t bad = 1;
-        HIP_CHECK(hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost));
+        uint32_t bad = 1, both[2] = {1, 0x7F800000u};
+        HIP_CHECK(hipMemcpy(both, d_bad, 8, hipMemcpyDeviceToHost));
+        bad = both[0];
+        std::memcpy(&g.max_row_norm, &both[1], 4);
         HIP_CHECK(hipFree(d_bad)); bufs_[7] = nullptr;
         if (bad) { HIP_CHECK(hipFree(du)); bufs_[6] = nullptr; du = nullptr; }
         g.vectors_u8 = du;
@@ -1675,7 +1735,7 @@ void DeviceIndex::upload(const HostIndex& h, int dev)
     (void)noalloc_scratch_for(dev, true);
     tune.read();
     func_lds_.clear();
-    dot4_off = false;
+    dot4_off = false; pack_off = false;
     version = h.version_;
     rows_epoch = h.rows_epoch_;
     learn_flags = 0; learn_ef = 0; learn_visit = 0; learn_c = 0; learn_mean = 0; learn_notes.clear();
@@ -1803,9 +1863,13 @@ void DeviceIndex::last_launch(uint32_t& lds_bytes, uint32_t& resident_per_cu, ui
 typedef void (*SearchKernel)(SearchArgs);
 
 template <bool SCALAR, int ROWS, bool BUCKET, int NBUF, bool IP = false, int NL = 0>
-static SearchKernel pick_wr(int wr, int wps = 4)
+static SearchKernel pick_wr(int wr, int wps = 4, bool packc = false)
 {
     if constexpr (ROWS == 3) { if (wr == 1 && wps == 6) return hnsw_search_kernel<SCALAR, 1, ROWS, BUCKET, NBUF, IP, NL, 6>; }
+    if constexpr (ROWS == 0 && !IP && NBUF == 2) {
+        if (packc && wr == 1) return hnsw_search_kernel<SCALAR, 1, 0, BUCKET, 2, false, NL, 4, true>;
+        if (packc && wr == 2) return hnsw_search_kernel<SCALAR, 2, 0, BUCKET, 2, false, NL, 4, true>;
+    }
     switch (wr) {
         case 0: return hnsw_search_kernel<SCALAR, 0, ROWS, BUCKET, NBUF, IP, NL>;
         case 1: return hnsw_search_kernel<SCALAR, 1, ROWS, BUCKET, NBUF, IP, NL>;
@@ -1815,26 +1879,26 @@ static SearchKernel pick_wr(int wr, int wps = 4)
 }
 
 template <bool BUCKET>
-static SearchKernel pick_rows(bool scalar, int wr, int rows, bool ip, int nl, int wps)
+static SearchKernel pick_rows(bool scalar, int wr, int rows, bool ip, int nl, int wps, bool packc)
 {
     if (ip && nl == 8) return pick_wr<false, 0, BUCKET, 2, true, 8>(wr);
     if (ip && nl == 6) return pick_wr<false, 0, BUCKET, 2, true, 6>(wr);
     if (ip) return pick_wr<false, 0, BUCKET, 2, true>(wr);
-    if (scalar && nl == 7) return pick_wr<true, 0, BUCKET, 2, false, 7>(wr);
-    if (scalar) return pick_wr<true, 0, BUCKET, 2>(wr);
+    if (scalar && nl == 7) return pick_wr<true, 0, BUCKET, 2, false, 7>(wr, 4, packc);
+    if (scalar) return pick_wr<true, 0, BUCKET, 2>(wr, 4, packc);
     if (rows == 3 && nl == 8) return pick_wr<false, 3, BUCKET, 2, false, 8>(wr, wps);
     if (rows == 3) return pick_wr<false, 3, BUCKET, 2>(wr, wps);
     if (rows == 1 && nl == 8) return pick_wr<false, 1, BUCKET, 2, false, 8>(wr);
     if (rows == 2 && nl == 8) return pick_wr<false, 2, BUCKET, 2, false, 8>(wr);
     if (rows == 1) return pick_wr<false, 1, BUCKET, 2>(wr);
     if (rows == 2) return pick_wr<false, 2, BUCKET, 2>(wr);
-    if (nl == 8) return pick_wr<false, 0, BUCKET, 2, false, 8>(wr);
-    if (nl == 6) return pick_wr<false, 0, BUCKET, 2, false, 6>(wr);
-    return pick_wr<false, 0, BUCKET, 2>(wr);
+    if (nl == 8) return pick_wr<false, 0, BUCKET, 2, false, 8>(wr, 4, packc);
+    if (nl == 6) return pick_wr<false, 0, BUCKET, 2, false, 6>(wr, 4, packc);
+    return pick_wr<false, 0, BUCKET, 2>(wr, 4, packc);
 }
 
 // deep: the float-row, probing-form kernel with six row pieces in flight and two wavefronts per query (see hnsw_search_kernel)
-static SearchKernel pick_kernel(bool scalar, int wr, int rows, bool bucket, bool ip, uint32_t d, bool generic /* the kernel for any row length */, bool deep = false, int wps = 4)
+static SearchKernel pick_kernel(bool scalar, int wr, int rows, bool bucket, bool ip, uint32_t d, bool generic /* the kernel for any row length */, bool deep = false, int wps = 4, bool packc = false)
 {
     if (deep && !scalar && rows == 0 && !bucket && !ip) {
         // (960 used dims = seven whole 128-dim items and one of four loads: the shape of the configuration this form exists for)
@@ -1842,7 +1906,7 @@ static SearchKernel pick_kernel(bool scalar, int wr, int rows, bool bucket, bool
         return pick_wr<false, 0, false, 6>(wr);
     }
     const int nl = generic ? 0 : row_shape_loads(d, scalar);
-    return bucket ? pick_rows<true>(scalar, wr, rows, ip, nl, wps) : pick_rows<false>(scalar, wr, rows, ip, nl, wps);
+    return bucket ? pick_rows<true>(scalar, wr, rows, ip, nl, wps, packc) : pick_rows<false>(scalar, wr, rows, ip, nl, wps, packc);
 }
 
 constexpr size_t kLdsPerCu = 163840;     // gfx950: 160 KB
@@ -2103,6 +2167,16 @@ void DeviceIndex::launch_tier(SearchCall& c)
     const bool std_heap = (flags & HNSW_AMD_W_STD_HEAP) != 0 || ef > 256;
     const int wr = std_heap ? 0 : (ef <= 64 ? 1 : (ef <= 128 ? 2 : 4));
     const int rows_kind = dot4 ? 3 : (u8 ? 1 : (q8 ? 2 : 0));
+    const bool wide_small = g.d > 256 && (uint64_t)a.nq_launch <= 4ull * (uint64_t)num_cus && !tune.no_deep_rows;   // (the two-wavefront form)
+    // Candidate-heap entries of four bytes (key in the top byte, node_order below) where that is provably enough: fewer
+    // than 2^24 rows, int32 keys, and no row so long that a query of ordinary length could be 250 away from it (the
+    // kernel checks its own query against the longest row and hands it back otherwise).  First launch only.
+    const bool packc = rows_kind == 0 && !ip && !(flags & HNSW_AMD_KEYS_FLOAT) && (wr == 1 || wr == 2) && !wide_small && tier == 0 &&
+                       g.n < (1u << 24) && g.max_row_norm <= 6.0f && !pack_off && !tune.no_pack_c;
+    c.packc = packc;
+    const int nl_shape = tune.generic_rows ? 0 : row_shape_loads(g.d, scalar);
+    a.c_words = packc ? 1u : 2u;
+    a.q_overlay = query_overlaid(nl_shape, rows_kind, scalar, (wide_small && !scalar && !ip) ? 6 : 2) ? 1u : 0u;
     constexpr size_t kMailBytes = 1024;
     SearchKernel kern_p = nullptr, kern_b = nullptr;
     bool deep_rows = false, deep_kernel = false;
@@ -2116,13 +2190,14 @@ void DeviceIndex::launch_tier(SearchCall& c)
         a.spill_pool = nullptr; a.spill_tables = 0; a.spill_slots = 0; a.vis_regions = 0; a.vis_magic = 0;
         a.hash_size = hash32_slots(want_visit); a.vis_rb = 0xFFFFFFFFu; a.vis_chunks = 0; a.ovf_size = 0;
         a.cap_c = std::max(((c.want_c0 << tier) + 31u) & ~31u, ((uint32_t)ef + 33u) & ~31u);      // W is sorted in C's space at the end
+        if (packc) a.cap_c = std::max(a.cap_c, 2u * a.cap_w);                                     // (W's entries are eight bytes)
         if (!std_heap && a.cap_w > a.cap_c) throw std::logic_error("search: W does not fit the space it borrows for the final sort");
         lds = search_lds_bytes(a, std_heap);
         // wide rows in a batch that leaves most of the chip idle: more loads in flight per query
         // (its 240 registers and two wavefronts per query leave a CU four queries: batches of up to four per CU)
-        deep_rows = g.d > 256 && (uint64_t)a.nq_launch <= 4ull * (uint64_t)num_cus && !tune.no_deep_rows;
-        kern_p = pick_kernel(scalar, wr, rows_kind, false, ip, g.d, tune.generic_rows, deep_rows, wps);     // probing forms
-        kern_b = pick_kernel(scalar, wr, rows_kind, true, ip, g.d, tune.generic_rows, false, wps);      // bucket form
+        deep_rows = wide_small;
+        kern_p = pick_kernel(scalar, wr, rows_kind, false, ip, g.d, tune.generic_rows, deep_rows, wps, packc);     // probing forms
+        kern_b = pick_kernel(scalar, wr, rows_kind, true, ip, g.d, tune.generic_rows, false, wps, packc);      // bucket form
         // LDS a query may use without lowering residency: the float-row kernels need 110-118 VGPRs, i.e. 4 waves per
         // SIMD = 16 one-wave workgroups per CU (the byte-row kernels could run 24, measured no faster than 16), and a
         // batch of fewer than 16 queries per CU needs even fewer slots (bounded, so that clearing the tables stays cheap).
@@ -2230,8 +2305,9 @@ void DeviceIndex::launch_tier(SearchCall& c)
         else if (a.vis_chunks) snprintf(form, sizeof form, "%u regions x %u slots of 16 bits + %u overflow%s", a.vis_regions, 8u * a.vis_chunks, a.ovf_size,
                                         a.spill_tables ? " + spill tables" : "");
         else snprintf(form, sizeof form, "%u slots of 16 bits in %u regions", a.hash_size, 1u << a.vis_rb);
-        fprintf(stderr, "[hnsw_amd] search launch: %u queries, ef=%d, tier %d (visited: %s for %u ids, C %u), LDS %zu B, resident queries per CU %d%s\n",
-                a.nq_launch, ef, tier, form, want_visit, a.cap_c, lds, nb, two_waves ? ", two wavefronts per query" : "");
+        fprintf(stderr, "[hnsw_amd] search launch: %u queries, ef=%d, tier %d (visited: %s for %u ids, C %u x %u B%s), LDS %zu B, resident queries per CU %d%s%s\n",
+                a.nq_launch, ef, tier, form, want_visit, a.cap_c, 4u * a.c_words, a.q_overlay ? ", query's copy overlaid" : "", lds, nb,
+                two_waves ? ", two wavefronts per query" : "", dot4 ? ", integer dot products" : "");
     }
     c.timed = tune.verbose && !no_alloc;
     if (c.timed) {
@@ -2325,6 +2401,7 @@ uint32_t DeviceIndex::finish(SearchCall* cp)
             fprintf(stderr, "[hnsw_amd]   %u of %u queries outgrew their scratch, %u used a spill table; largest visited set %u, room asked of C %u\n",
                     nfail, a.nq_launch, std::min(r[3], a.spill_tables), r[1], r[2]);
         if (c.dot4 && c.tier == 0 && r[6] > c.nq / 2u) dot4_off = true;
+        if (c.packc && c.tier == 0 && r[6] > c.nq / 2u) pack_off = true;
         if (nfail == 0) break;
         c.retried += nfail;
         a.qmap = c.cur + kFailHeader; a.nq_launch = nfail;
