@@ -68,7 +68,17 @@ def main():
                     help="float: the construction searches use float candidate keys (a regular HNSW graph, not the reference's; "
                          "several times faster to build on unit-norm data)")
     ap.add_argument("--sweep", default="", help="comma-separated ef values: report recall and QPS for each instead of one operating point")
+    ap.add_argument("--preset", default="", choices=["", "sift1m", "deep100m"],
+                    help="a named configuration: sift1m = the defaults; deep100m = DEEP-96-shaped 100M base split over the ranks "
+                         "(--gpus 8: 12.5M rows per GPU), GPU-assisted build with float construction keys, reference int32 search keys, "
+                         "no replicated leg.  --base-size after the preset scales it down for rehearsals")
     args = ap.parse_args()
+    if args.preset == "deep100m":
+        defaults = ap.parse_args([])
+        for name, value in (("kind", "deep"), ("n", 100_000_000), ("build", "gpu"), ("build_keys", "float"), ("no_alongside", True),
+                            ("cpu_baseline", "none")):
+            if getattr(args, name) == getattr(defaults, name):      # (an explicit flag wins over the preset)
+                setattr(args, name, value)
 
     import torch
     import torch.distributed as dist
@@ -390,6 +400,36 @@ def main():
     # ---- N=1: batches in flight (not part of `value`): the search call in two halves lets the next batch start while
     #      the last queries of the previous one are still running, which is what the lone 10 000-query batch lacks ----
     pipelined = None
+    if parts > 1 and backend == "nccl" or (parts > 1 and os.environ.get("HNSW_AMD_BENCH_PIPELINE_GLOO")):
+        # every rank's search of batch i+1 runs while batch i is all-gathered and merged (two slots, two streams)
+        def run_sharded(nb):
+            pending = None
+            last = None
+            for i in range(nb):
+                hnd = sh.search_begin(q_t, ef, k, slot=i % 2)
+                if pending is not None:
+                    last = sh.search_finish(pending)
+                pending = hnd
+            last = sh.search_finish(pending)
+            torch.cuda.synchronize()
+            return last
+
+        run_sharded(4)
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        nb = max(args.steps, 4)
+        li_p, ld_p, _ = run_sharded(nb)
+        dist.barrier()
+        torch.cuda.synchronize()
+        tp = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=cdev)
+        dist.all_reduce(tp, op=dist.ReduceOp.MAX)
+        dtp = float(tp.item())
+        pipelined = {"2_in_flight": {"value": round(nq * nb / dtp, 1), "unit": "queries/s", "batches": nb, "queries_per_batch": nq,
+                                     "ms_per_batch": round(dtp / nb * 1e3, 4),
+                                     "results_equal_the_blocking_call": bool(torch.equal(li_p, out_ids))},
+                     "what": "every rank searches batch i+1 while batch i is all-gathered and merged (two slots on two streams); "
+                             "slowest rank's host clock over all batches, merged outputs complete"}
     if world == 1 and not args.sweep:
         pipelined = {}
         for depth in (2, 3):

@@ -110,5 +110,17 @@ def test_exchange_over_rccl_with_a_world_of_one():
         torch.cuda.synchronize()
         oi, od, _ = oracle.OracleIndex(sh.index.export_flat(), base).search(q, ef, out_k=k)
         assert_same_results(ids.cpu().numpy().view(np.uint32), ds.cpu().numpy(), oi, od, what="one rank over RCCL")
+        # the same in two halves, two batches in flight: the second batch searches while the first is gathered and merged
+        q2 = datagen.make("deep", nq, seed=13, stream=1)
+        qa, qb = torch.from_numpy(q).cuda(), torch.from_numpy(q2).cuda()
+        for _ in range(2):
+            ha = sh.search_begin(qa, ef, k, slot=0)
+            hb = sh.search_begin(qb, ef, k, slot=1)
+            ia, da, ea = sh.search_finish(ha)
+            ib, db, eb = sh.search_finish(hb)
+            ea.synchronize(); eb.synchronize()
+            oi2, od2, _ = oracle.OracleIndex(sh.index.export_flat(), base).search(q2, ef, out_k=k)
+            assert_same_results(ia.cpu().numpy().view(np.uint32), da.cpu().numpy(), oi, od, what="pipelined, first batch")
+            assert_same_results(ib.cpu().numpy().view(np.uint32), db.cpu().numpy(), oi2, od2, what="pipelined, second batch")
     finally:
         dist.destroy_process_group()
