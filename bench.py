@@ -662,6 +662,7 @@ def main():
                        "ef": ef, "recall_at_10": round(recall, 4), "reference_precision_top11": prec_ref,
                        "timed_step_output": f"the first k={k} entries of every W_ (the reference leaves all ef entries sorted in W_; "
                                             f"the parity check of the cpu_baseline leg compares all ef)",
+                       "host_peak_rss_gb": round(__import__("resource").getrusage(__import__("resource").RUSAGE_SELF).ru_maxrss / 1e6, 2),
                        "ef_sweep": sweep, "build_s": round(build_s, 1), "build_threads": args.build_threads, "build_keys": args.build_keys, "build": args.build,
                        "ground_truth": dict(gt_info, method="exact brute force, f32-input MFMA kernel of this library")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
