@@ -128,7 +128,7 @@ def main():
     # ---- build (host, concurrent inserts) or load from the cache directory ----
     h = HNSW(16, 16, 200, device=local_rank)
     cache = os.environ.get("HNSW_AMD_BENCH_CACHE")
-    cpath = os.path.join(cache, f"{args.kind}_n{args.n}_s{parts}_r{prank}{'_fk' if args.build_keys == 'float' else ''}{'_gb' if args.build == 'gpu' else ''}.npz") if cache else None
+    cpath = os.path.join(cache, f"{args.kind}_n{args.n}_s{parts}_r{prank}{'_fk' if args.build_keys == 'float' else ''}{'_gb' if args.build == 'gpu' else ''}{'_sc' if args.dist == 'scalar' else ''}.npz") if cache else None
     t0 = time.time()
     if cpath and os.path.exists(cpath):
         from hnsw_amd.flatgraph import FlatGraph
@@ -138,6 +138,7 @@ def main():
         h.init(d, hi - lo)
         if args.build_keys == "float":
             h.set_build_float_keys(True)
+        h.set_build_distance(args.dist)           # the same reference build for insert() and for the search
         step_rows = 500_000       # in pieces, so a long build keeps reporting progress
         for r0 in range(0, hi - lo, step_rows):
             h.insert_batch(base[r0:r0 + step_rows], threads=args.build_threads, gpu=(args.build == "gpu"))

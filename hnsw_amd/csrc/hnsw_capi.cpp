@@ -126,7 +126,7 @@ static void assisted_candidates(void* ctx, const float* queries, uint32_t nq, in
     hnsw_amd_index* h = static_cast<hnsw_amd_index*>(ctx);
     if (device_has_rows(h)) h->dev.refresh_graph(h->host);
     else h->dev.upload(h->host, h->device);
-    const uint32_t flags = HNSW_AMD_DIST_SSE | (h->host.build_float_keys_ ? HNSW_AMD_KEYS_FLOAT : HNSW_AMD_KEYS_INT32);
+    const uint32_t flags = (h->host.dist_scalar_ ? HNSW_AMD_DIST_SCALAR : HNSW_AMD_DIST_SSE) | (h->host.build_float_keys_ ? HNSW_AMD_KEYS_FLOAT : HNSW_AMD_KEYS_INT32);
     const int rc = hnsw_amd_search_batch(h, queries, nq, ef, (uint32_t)ef, flags, ids, dist, cnt, nullptr);
     if (rc != HNSW_AMD_OK) throw std::runtime_error(g_err);
 }
@@ -149,6 +149,15 @@ int hnsw_amd_insert_batch_assisted(hnsw_amd_index* h, const float* rows, uint32_
 int hnsw_amd_set_build_float_keys(hnsw_amd_index* h, int on)
 {
     return guarded([&] { REQUIRE(h, "set_build_float_keys: index is NULL"); h->host.build_float_keys_ = on != 0; });
+}
+
+int hnsw_amd_set_build_distance(hnsw_amd_index* h, uint32_t dist_flag)
+{
+    return guarded([&] {
+        REQUIRE(h, "set_build_distance: index is NULL");
+        REQUIRE(dist_flag == HNSW_AMD_DIST_SSE || dist_flag == HNSW_AMD_DIST_SCALAR, "set_build_distance: HNSW_AMD_DIST_SSE or HNSW_AMD_DIST_SCALAR");
+        h->host.dist_scalar_ = dist_flag == HNSW_AMD_DIST_SCALAR;
+    });
 }
 
 int hnsw_amd_sync_device(hnsw_amd_index* h, int device)

@@ -66,6 +66,25 @@ float distance_sse_order(const float* a, const float* b, uint32_t d)
     return ((t[0] + t[1]) + t[2]) + t[3];
 }
 
+// The plain loop of src/hnsw.h:387-400 as g++ 11 compiles it for the reference's scalar build: all d dims, one running
+// sum in index order; the loop is unrolled by four with each square rounded before it is added, and only the remainder
+// loop (the last d % 4 dims) is contracted into fused multiply-adds.  (This file is built with -ffp-contract=off: the
+// fused steps are the ones spelled out.)
+float distance_scalar_order(const float* a, const float* b, uint32_t d)
+{
+    float r = 0.0f;
+    const uint32_t d4 = d & ~3u;
+    uint32_t i = 0;
+    for (; i < d4; i++) { const float t = a[i] - b[i]; const float p = t * t; r = r + p; }
+    for (; i < d; i++) { const float t = a[i] - b[i]; r = std::fmaf(t, t, r); }
+    return r;
+}
+
+float HostIndex::dist(const float* a, const float* b) const
+{
+    return dist_scalar_ ? distance_scalar_order(a, b, vector_size_) : distance_sse_order(a, b, vector_size_);
+}
+
 // Four rows against one query at once: same arithmetic per row, the four dependent
 // FMA chains interleaved so the core's FMA latency is hidden.
 static inline void distance_sse_order_x4(const float* q, const float* r0, const float* r1, const float* r2,
@@ -206,7 +225,7 @@ void HostIndex::search_layer_one(int layer, const float* q, Scratch& s)
         for (uint32_t j = 0; j < cnt; j++) {
             uint32_t id = po[j];
             if (s.test_and_set(id)) continue;
-            float dist = distance_sse_order(row(id), q, vector_size_);
+            float dist = this->dist(row(id), q);
             if (dist < cur.distance) { change = true; cur.slot = ps[j]; cur.distance = dist; cur.node_order = id; }
         }
     }
@@ -252,9 +271,10 @@ void HostIndex::search_layer(int layer, const float* q, int ef, Scratch& s)
             }
         }
         uint32_t j = 0;
-        for (; j + 4 <= m; j += 4)
-            distance_sse_order_x4(q, row(s.ids[j]), row(s.ids[j + 1]), row(s.ids[j + 2]), row(s.ids[j + 3]), d, &s.dist[j]);
-        for (; j < m; j++) s.dist[j] = distance_sse_order(q, row(s.ids[j]), d);
+        if (!dist_scalar_)
+            for (; j + 4 <= m; j += 4)
+                distance_sse_order_x4(q, row(s.ids[j]), row(s.ids[j + 1]), row(s.ids[j + 2]), row(s.ids[j + 3]), d, &s.dist[j]);
+        for (; j < m; j++) s.dist[j] = this->dist(q, row(s.ids[j]));
         for (j = 0; j < m; j++) {
             const float dist = s.dist[j];
             if (dist < f || W.size() < (size_t)ef) {
@@ -281,7 +301,7 @@ void HostIndex::select_neighbors(std::vector<Neighbor>& W, std::vector<Neighbor>
     for (size_t i = 2; i < W.size() && sel < M; i++) {
         bool keep = true;
         for (size_t j = 0; j < R.size(); j++) {
-            float dist = distance_sse_order(row(W[i].node_order), row(R[j].node_order), vector_size_);
+            float dist = this->dist(row(W[i].node_order), row(R[j].node_order));
             if (dist < W[i].distance) { keep = false; break; }
         }
         if (keep) { R.push_back(W[i]); sel++; }
@@ -363,7 +383,7 @@ void HostIndex::insert_one(uint32_t id, const float* q, int level, const uint32_
     s.W.clear();
     if (L >= 0) {
         const LayerStore& top = layers_[L];
-        float dist = distance_sse_order(row(top.ep_order), q, vector_size_);
+        float dist = this->dist(row(top.ep_order), q);
         s.test_and_set(top.ep_order);
         s.W.push_back(Neighbor{dist, top.ep_order, top.ep_slot});
     }

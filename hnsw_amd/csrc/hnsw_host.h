@@ -61,6 +61,9 @@ public:
     std::vector<LayerStore> layers_;
     std::vector<float> vector_data_;   // max_node_count_ x vector_size_, row = node_order
     bool build_float_keys_ = false;    // construction searches keyed by the float distance instead of its int32 truncation
+    bool dist_scalar_ = false;         // insert() computes distances as the reference's -DNO_MANUAL_VECTORIZATION build does
+                                       // (src/hnsw.h:387-400: all d dims, one running sum) instead of the shipped SSE loop
+    float dist(const float* a, const float* b) const;   // the distance insert() uses
     uint64_t version_ = 0;             // bumped by every mutation (device copy refresh)
     uint64_t rows_epoch_ = 0;          // identifies the contents of vector_data_'s table: a new value (unique in the process) whenever
                                        // init / load_graph / import_flat replaces it, so a device copy of the rows knows whose rows it holds
@@ -109,5 +112,7 @@ private:
 
 // Squared L2 exactly as the reference's shipped build computes it (src/hnsw.h:334-383).
 float distance_sse_order(const float* a, const float* b, uint32_t d);
+// ... and as its -DNO_MANUAL_VECTORIZATION build computes it (src/hnsw.h:387-400 compiled by g++ 11 -O3 -march=native).
+float distance_scalar_order(const float* a, const float* b, uint32_t d);
 
 }  // namespace hnsw_amd

@@ -80,6 +80,11 @@ class HNSW:
         graph, several times faster to build on unit-norm data, but no longer the reference's adjacency."""
         capi.check(capi.lib().hnsw_amd_set_build_float_keys(self._h, 1 if on else 0))
 
+    def set_build_distance(self, dist: str) -> None:
+        """"sse": insert() computes distances as the shipped reference build does; "scalar": as its
+        -DNO_MANUAL_VECTORIZATION build does (all d dims, one running sum)."""
+        capi.check(capi.lib().hnsw_amd_set_build_distance(self._h, {"sse": capi.DIST_SSE, "scalar": capi.DIST_SCALAR}[dist]))
+
     def sync_device(self, device: int | None = None) -> None:
         if device is not None:
             self.device = device

@@ -136,6 +136,12 @@ int hnsw_amd_insert_batch_assisted(hnsw_amd_index* h, const float* rows, uint32_
  * the construction search never stops early, and turning this on makes the build several times faster; the result
  * is a regular HNSW graph, not the reference's adjacency. */
 int hnsw_amd_set_build_float_keys(hnsw_amd_index* h, int on);
+/* Which of the reference's two builds insert() reproduces: HNSW_AMD_DIST_SSE (default) = the shipped one, whose distance
+ * (src/hnsw.h:334-383) uses the first 16*floor(d/16) dims; HNSW_AMD_DIST_SCALAR = a -DNO_MANUAL_VECTORIZATION build
+ * (src/hnsw.h:2, 387-400), whose plain loop uses all d dims — the reference build to compare with when d is not a
+ * multiple of 16 (GloVe-100).  insert() and the searches of one reference binary use the same distance, so an index
+ * built this way is searched with the same flag.  Sequential inserts reproduce that build's adjacency. */
+int hnsw_amd_set_build_distance(hnsw_amd_index* h, uint32_t dist_flag);
 
 /* HNSW::aproximateKnn(float* q, int k, int ef) — src/hnsw.cpp:373-449.  The reference leaves
  * its result in the public member W_ (up to ef entries, ascending squared-L2 distance; k is

@@ -218,6 +218,8 @@ public:
     }
     // construction searches keyed by the float distance instead of the int32 truncation (see hnsw_amd.h)
     void setBuildFloatKeys(bool on) { check(hnsw_amd_set_build_float_keys(h_, on ? 1 : 0)); }
+    // insert() with the distance of a -DNO_MANUAL_VECTORIZATION build of the reference (src/hnsw.h:387-400) instead of the shipped SSE loop
+    void setBuildScalarDistance(bool on) { check(hnsw_amd_set_build_distance(h_, on ? HNSW_AMD_DIST_SCALAR : HNSW_AMD_DIST_SSE)); }
 
     // src/hnsw.cpp:373-449: result in W_, up to ef entries ascending; k is ignored as upstream
     void aproximateKnn(float* q, int k, int ef)

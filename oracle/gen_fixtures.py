@@ -45,6 +45,7 @@ CASES = {
 HASH_CASES = {
     "int_d128_n20000": dict(kind="sift", d=128, n=20000, ctor=(16, 16, 200), build="sse"),
     "unit_d96_n10000": dict(kind="deep", d=96, n=10000, ctor=(16, 16, 200), build="sse"),
+    "unit_d100_n10000_scalar": dict(kind="glove", d=100, n=10000, ctor=(16, 16, 200), build="scalar"),
 }
 
 

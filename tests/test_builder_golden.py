@@ -11,16 +11,14 @@ from hnsw_amd import HNSW, datagen
 from hnsw_amd import capi
 from tests.helpers import GOLD, Golden, golden_names
 
-# the scalar-distance fixture was built by a -DNO_MANUAL_VECTORIZATION reference; the host
-# builder implements the shipped (SSE-order) distance only
-SSE_BUILT = [n for n in golden_names() if not n.endswith("_scalar")]
-
-
-@pytest.mark.parametrize("name", SSE_BUILT)
+# (the fixture named *_scalar was built by a -DNO_MANUAL_VECTORIZATION reference: insert() then computes distances with
+# that build's plain loop, set_build_distance("scalar"))
+@pytest.mark.parametrize("name", golden_names())
 def test_sequential_build_reproduces_reference_graph(name):
     g = Golden(name)
     M, Mmax, efC = g.meta["ctor"]
     h = HNSW(M, Mmax, efC)
+    h.set_build_distance(g.meta["build"])
     h.init(g.meta["d"], g.meta["n"])
     for row in g.base[:7]:          # the one-at-a-time entry point ...
         h.insert(row)
@@ -31,13 +29,14 @@ def test_sequential_build_reproduces_reference_graph(name):
     assert h.actual_node_count_ == g.meta["n"] - 1
 
 
-@pytest.mark.parametrize("name", ["int_d128_n20000", "unit_d96_n10000"])
+@pytest.mark.parametrize("name", ["int_d128_n20000", "unit_d96_n10000", "unit_d100_n10000_scalar"])
 def test_larger_build_matches_reference_adjacency_hash(name):
     with open(os.path.join(GOLD, "adjacency_hashes.json")) as f:
         rec = json.load(f)[name]
     base = datagen.make(rec["kind"], rec["n"], seed=rec["seed"], stream=0, d=rec["d"])
     assert datagen.checksum(base) == rec["base_sha"]
     h = HNSW(*rec["ctor"])
+    h.set_build_distance(rec["build"])
     h.init(rec["d"], rec["n"])
     h.insert_batch(base, threads=1)
     fg = h.export_flat()

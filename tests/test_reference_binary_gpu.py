@@ -36,6 +36,7 @@ def test_kernel_matches_the_reference_binary(tmp_path, kind, build, flags, n, ef
     base = datagen.make(kind, n, seed=21)
     q = datagen.make(kind, nq, seed=21, stream=1)
     h = HNSW(16, 16, 100)
+    h.set_build_distance(build)              # (insert() and the search of one reference build use the same distance)
     h.init(base.shape[1], n)
     h.insert_batch(base, threads=16)
     gpath, qpath, rpath = (str(tmp_path / x) for x in ("g.bin", "q.bin", "r.bin"))
@@ -87,10 +88,9 @@ def test_index_built_and_saved_by_the_reference(tmp_path, kind, build, flags, n,
         ids, dist, cnt = h.search_batch(q, ef, flags=flags)
         assert np.array_equal(cnt, r_cnt)
         assert_same_results(ids, dist, r_ids, r_d, what=f"{kind} ef={ef}, index built by the reference")
-    if build != "sse":
-        return          # (the host builder implements the shipped SSE-order distance only)
-    # the sequential build of this library on the same rows: the same graph
+    # the sequential build of this library on the same rows, with the distance of that reference build: the same graph
     mine = HNSW(16, 16, efc)
+    mine.set_build_distance(build)
     mine.init(d, n)
     mine.insert_batch(base, threads=1)
     a, b = mine.export_flat(), h.export_flat()

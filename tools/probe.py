@@ -40,6 +40,7 @@ else:
     h.init(d, a.n)
     if a.build_keys == "float":
         h.set_build_float_keys(True)
+    h.set_build_distance(a.dist)
     h.insert_batch(base, threads=16, gpu=True)
     if a.cache:
         np.savez(a.cache, **h.export_flat().to_npz_dict())
