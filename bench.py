@@ -353,9 +353,10 @@ def main():
                               torch.cuda.current_stream().cuda_stream, flags)
         torch.cuda.synchronize()
         launch_info = h.last_launch_info()
-        if args.rows == "f32" and args.dist == "sse":
+        if args.rows == "f32":
             rows_per_wave = max(32, int(round(float(st["n_dist"].mean()) / 32.0)) * 32)
-            c_ms, c_bytes = h.gather_ceiling(nq, rows_per_wave, launch_info["lds_bytes_per_query"], torch.cuda.current_stream().cuda_stream)
+            c_ms, c_bytes = h.gather_ceiling(nq, rows_per_wave, launch_info["lds_bytes_per_query"], torch.cuda.current_stream().cuda_stream,
+                                             scalar=(args.dist == "scalar"))
             ceiling_gbs = c_bytes / (c_ms * 1e-3) / 1e9
     # HBM bytes per launch from the PMC passes of tools/pmc_passes.sh over this same workload
     # (FETCH_SIZE doubled as the gfx950 counter requires, plus WRITE_SIZE); a profile of

@@ -72,7 +72,7 @@ SYMBOLS = {
                                                  C.c_void_p, C.c_void_p, C.c_void_p, _f32p]),
     "hnsw_amd_merge_topk_device": (C.c_int, [C.c_void_p, C.c_void_p, _u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                              C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "hnsw_amd_gather_ceiling_device": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, _f32p, C.POINTER(C.c_uint64)]),
+    "hnsw_amd_gather_ceiling_device": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, _f32p, C.POINTER(C.c_uint64)]),
     "hnsw_amd_last_launch_info": (C.c_int, [C.c_void_p, _u32p, _u32p, _u32p]),
     "hnsw_amd_vector_data": (C.c_int, [C.c_void_p, C.POINTER(_f32p)]),
     "hnsw_amd_get_info": (C.c_int, [C.c_void_p, _i32p, _i32p, _i32p, _i32p, _u32p, _i32p, _i32p, _u32p]),

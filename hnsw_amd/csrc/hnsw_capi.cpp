@@ -358,13 +358,14 @@ int hnsw_amd_merge_topk_device(const float* d_dist, const uint32_t* d_ids, const
     });
 }
 
-int hnsw_amd_gather_ceiling_device(hnsw_amd_index* h, uint32_t n_waves, uint32_t rows_per_wave, uint32_t lds_bytes_per_wave, void* stream,
-                                   float* ms, uint64_t* bytes)
+int hnsw_amd_gather_ceiling_device(hnsw_amd_index* h, uint32_t n_waves, uint32_t rows_per_wave, uint32_t lds_bytes_per_wave, uint32_t dist_flag,
+                                   void* stream, float* ms, uint64_t* bytes)
 {
     return guarded([&] {
         REQUIRE(h && ms && bytes, "gather_ceiling_device: NULL argument");
+        REQUIRE(dist_flag == HNSW_AMD_DIST_SSE || dist_flag == HNSW_AMD_DIST_SCALAR, "gather_ceiling_device: HNSW_AMD_DIST_SSE or HNSW_AMD_DIST_SCALAR");
         ensure_device_copy(h);
-        *ms = h->dev.gather_ceiling(n_waves, rows_per_wave, lds_bytes_per_wave, stream, *bytes);
+        *ms = h->dev.gather_ceiling(n_waves, rows_per_wave, lds_bytes_per_wave, stream, *bytes, dist_flag == HNSW_AMD_DIST_SCALAR);
     });
 }
 

@@ -147,7 +147,7 @@ public:
     // Diagnostic: milliseconds of one launch in which n_waves wavefronts each read rows_per_wave random rows of the
     // vector table with the search kernel's loads and distance arithmetic and nothing else; `bytes` = what the
     // search's counters would charge for those rows.  lds_bytes per wavefront sets the residency.
-    float gather_ceiling(uint32_t n_waves, uint32_t rows_per_wave, uint32_t lds_bytes, void* stream, uint64_t& bytes);
+    float gather_ceiling(uint32_t n_waves, uint32_t rows_per_wave, uint32_t lds_bytes, void* stream, uint64_t& bytes, bool scalar = false);
     // copy_back: a device-to-host copy (pinned destination) queued behind every launch, before the report.
     typedef decltype(SearchCall::copy_back) CopyBack;
     // begin: sizes the batch's scratch from what is known, launches it on `stream` and queues the launch's report; returns

@@ -711,6 +711,98 @@ __device__ __forceinline__ void batch_distance(const DistCtx& c, const float* co
     }
 }
 
+// Scalar order on TWO lanes per row.  The running sum of the reference's plain loop (src/hnsw.h:387-400) is one sequential
+// chain of d additions per row, so a wave instruction can advance at most as many rows as it has lanes working on
+// different rows: with four lanes per row (the form above) a list of 32 rows takes two passes in each of which three
+// lanes of four compute values nobody reads.  Here the two rows of a quad are served at once: lanes j and j + 2 of quad r
+// hold row 2r + (j & 1) (lane j & 1 is the lane that holds the row's id in merged form), the lower lane ("A") the
+// elements that feed lane sums 0 and 1 of the SSE layout — the first 64 bytes of every stored 128-byte line — the upper
+// ("B") those of sums 2 and 3.  Dims 4k, 4k+1 of a line are then A's k-th elements, dims 4k+2, 4k+3 B's, and the running
+// sum alternates: two additions in A, over to B (a DPP operand: quad_perm [2,3,0,1]), two additions in B, back to A.  One
+// instruction stream serves both: x = partner(x) + p0; x = x + p1, twice per k — the lane whose turn it is not computes
+// values that its next "partner(x)" overwrites.  Per 4 dims of 32 rows: 2 sub + 2 mul + 4 add = 8 instructions, against
+// 12 for the four-lane form (two passes of 6); a line is touched by four load instructions of 32 bytes per row.
+// `rowp`: this lane's row + 16 floats for a B lane; `act`: the row takes part.  The result is returned in the A lane.
+// NL = 7: rows of 97..112 dims without a fused tail (d = 100): three whole lines and the first four k-steps of the fourth
+// (what lies past d there is zero padding in row and query: adding the square of 0 leaves the sum as it is).
+__device__ __forceinline__ float quad_partner(float x)
+{
+    return __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(x), 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+}
+
+template <int KSTEPS, bool FUSED>
+__device__ __forceinline__ void consume_line_scalar2(const float* qp /* the lane's 16 floats of the query's line */, uint32_t k0 /* element index of the line's first k-step */,
+                                                     uint32_t kf, const float4 (&v)[4], float& x)
+{
+    // v[0], v[1]: the lane's first sum's elements k = 0..7; v[2], v[3]: its second sum's
+#pragma unroll
+    for (int k = 0; k < KSTEPS; k++) {
+        const float4 qa = *reinterpret_cast<const float4*>(qp + 4 * (k >> 2)), qb = *reinterpret_cast<const float4*>(qp + 8 + 4 * (k >> 2));
+        const float t0 = f4_get(v[k >> 2], k & 3) - f4_get(qa, k & 3);
+        const float t1 = f4_get(v[2 + (k >> 2)], k & 3) - f4_get(qb, k & 3);
+        if (!FUSED || k0 + (uint32_t)k != kf) {
+            const float p0 = t0 * t0, p1 = t1 * t1;
+            x = quad_partner(x) + p0; x = x + p1;
+            x = quad_partner(x) + p0; x = x + p1;
+        } else {
+            x = __builtin_fmaf(t0, t0, quad_partner(x)); x = __builtin_fmaf(t1, t1, x);
+            x = __builtin_fmaf(t0, t0, quad_partner(x)); x = __builtin_fmaf(t1, t1, x);
+        }
+    }
+}
+
+__device__ __forceinline__ void issue_line_scalar2(const float* p, float4 (&v)[4])
+{
+#pragma unroll
+    for (int t = 0; t < 4; t++) v[t] = *reinterpret_cast<const float4*>(p + 4 * t);
+}
+
+template <int NL>
+__device__ __forceinline__ float batch_distance_scalar2(const DistCtx& c, const float* rowp, bool act, int lane)
+{
+    static_assert(NL == 0 || NL == 7, "scalar order: the kernel for any row length, or the one for 97..112 dims");
+    const float* qp = c.qs + 16 * ((lane >> 1) & 1);
+    float x = 0.0f;
+    if constexpr (NL == 7) {
+        float4 b0[4], b1[4], b2[4], b3[4];
+        if (act) {
+            issue_line_scalar2(rowp, b0); issue_line_scalar2(rowp + 32, b1); issue_line_scalar2(rowp + 64, b2);
+            b3[0] = *reinterpret_cast<const float4*>(rowp + 96); b3[2] = *reinterpret_cast<const float4*>(rowp + 96 + 8);
+            b3[1] = b3[0]; b3[3] = b3[2];
+        }
+        if (act) {
+            consume_line_scalar2<8, false>(qp, 0, 0, b0, x);
+            consume_line_scalar2<8, false>(qp + 32, 0, 0, b1, x);
+            consume_line_scalar2<8, false>(qp + 64, 0, 0, b2, x);
+            consume_line_scalar2<4, false>(qp + 96, 0, 0, b3, x);
+        }
+    } else {
+        // any row length: lines of 32 dims, four in flight; the k-step that holds the last d % 4 dims is fused
+        // (c.kf, counted in k-steps over the whole row), and nothing past the last line that holds a dim is read
+        const uint32_t nlines = (c.d4 + (c.kf != 0xFFFFFFFFu ? 4u : 0u) + 31u) >> 5;
+        float4 buf[4][4];
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+            if ((uint32_t)b < nlines && act) issue_line_scalar2(rowp + 32 * b, buf[b]);
+        for (uint32_t l = 0; l < nlines; l += 4) {
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+                if (l + b < nlines) {
+                    if (act) {
+                        if (c.kf - 8u * (l + b) < 8u) consume_line_scalar2<8, true>(qp + 32 * (l + b), 8u * (l + b), c.kf, buf[b], x);
+                        else consume_line_scalar2<8, false>(qp + 32 * (l + b), 0, 0, buf[b], x);
+                        if (l + b + 4 < nlines) issue_line_scalar2(rowp + 32 * (l + b + 4), buf[b]);
+                    }
+                }
+        }
+    }
+    // After a whole k-step the sum sits in the B lane: one more exchange hands it to the A lane, which is the lane that
+    // holds the row in merged form and the only one whose distance is read (the B lane receives a value nobody uses).
+    // Unconditional on purpose: a cross-lane read under a lane-dependent condition is executed with the source lanes
+    // switched off and returns nothing.
+    return quad_partner(x);
+}
+
 // The same for byte rows (SSE order only): row[s] points at this lane's 32 bytes of the row's first block.
 // NL = 8: a kernel built for rows of 128 dims (one block, known at compile time: the loop below unrolls into straight-line code).
 template <int NL = 0>
@@ -827,10 +919,25 @@ __device__ __forceinline__ void rows_distance(const DeviceGraph& g, const DistCt
         if constexpr (ROWS == 3) batch_distance_dot4<NL>(c, row, act, out, lane, qr);
         else batch_distance_u8<NL>(c, row, act, out, lane, qr);
     } else {
-        const float* row[RM::kSub];
+        if constexpr (SCALAR) {
+            // two lanes per row: lanes j and j + 2 of a quad serve the row that lane j & 1 holds in merged form
+            // (one wavefront per query: the two-wavefront form, SUB >= 0, reads float rows in SSE order only and never gets here)
+            // (plain values first: a lane-dependent choice between two array elements would be made in scratch memory)
+            const bool odd = (lane & 1) != 0;
+            const uint32_t id_even = id[0], id_odd = id[RM::kSub - 1];
+            const bool act_even = act[0], act_odd = act[RM::kSub - 1];
+            const uint32_t my_id = odd ? id_odd : id_even;
+            const bool my_act = odd ? act_odd : act_even;
+            const float* rowp = g.vectors + (size_t)my_id * g.row_stride + 16u * ((lane >> 1) & 1);
+            const float r = batch_distance_scalar2<NL>(c, rowp, my_act, lane);
 #pragma unroll
-        for (int s = 0; s < RM::kSub; s++) row[s] = g.vectors + (size_t)id[s] * g.row_stride + 8u * (lane & 3);
-        batch_distance<SCALAR, NBUF, IP, SUB, NL>(c, row, act, out, lane, qr);
+            for (int s = 0; s < RM::kSub; s++) out[s] = r;
+        } else {
+            const float* row[RM::kSub];
+#pragma unroll
+            for (int s = 0; s < RM::kSub; s++) row[s] = g.vectors + (size_t)id[s] * g.row_stride + 8u * (lane & 3);
+            batch_distance<SCALAR, NBUF, IP, SUB, NL>(c, row, act, out, lane, qr);
+        }
     }
 }
 
@@ -1522,7 +1629,7 @@ __global__ __launch_bounds__(NBUF == 2 ? 64 : 128) __attribute__((amdgpu_waves_p
 // vector table with the search kernel's own loads and arithmetic (rows_distance: four lanes per row, 32 rows
 // in flight), but with no heaps, no visited set, no neighbour lists and no dependence of one batch on the
 // previous one.  Residency is set the way the search kernel's is, by the dynamic LDS size.
-template <int NL>
+template <int NL, bool SCALAR = false>
 __global__ __launch_bounds__(64) void gather_ceiling_kernel(DeviceGraph g, uint32_t iters, float* __restrict__ out)
 {
     extern __shared__ __align__(16) uint32_t smem[];
@@ -1531,7 +1638,7 @@ __global__ __launch_bounds__(64) void gather_ceiling_kernel(DeviceGraph g, uint3
     const uint32_t qpad = (g.d + 63u) & ~63u;
     for (uint32_t i = lane; i < qpad; i += 64) qs[i] = 0.0f;
     LDS_SYNC();
-    const DistCtx dc = make_dist_ctx<false>(qs, g.d);
+    const DistCtx dc = make_dist_ctx<SCALAR>(qs, g.d);
     QRegs<NL> qr;
     qregs_load(qr, qs, lane);
     auto mix = [](uint32_t x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x; };
@@ -1542,7 +1649,7 @@ __global__ __launch_bounds__(64) void gather_ceiling_kernel(DeviceGraph g, uint3
         uint32_t rid[2]; float dj[2];
         rid[0] = __umulhi(mix(seed + it * 32u + 2u * r), g.n);
         rid[1] = __umulhi(mix(seed + it * 32u + 2u * r + 1u), g.n);
-        rows_distance<false, 0, 2, false, -1, NL>(g, dc, rid, act, dj, lane, qr);
+        rows_distance<SCALAR, 0, 2, false, -1, NL>(g, dc, rid, act, dj, lane, qr);
         acc += dj[0] + dj[1];
     }
     if (lane == 0) out[blockIdx.x] = acc;
@@ -1808,7 +1915,7 @@ void DeviceIndex::ensure_quantized(const HostIndex& h)
     g.vectors_q8 = dq;
 }
 
-float DeviceIndex::gather_ceiling(uint32_t n_waves, uint32_t rows_per_wave, uint32_t lds_bytes, void* stream_v, uint64_t& bytes)
+float DeviceIndex::gather_ceiling(uint32_t n_waves, uint32_t rows_per_wave, uint32_t lds_bytes, void* stream_v, uint64_t& bytes, bool scalar)
 {
     if (device < 0) throw std::logic_error("gather_ceiling: index not on a device");
     if (n_waves == 0 || rows_per_wave < 32) throw std::invalid_argument("gather_ceiling: need at least one wavefront and 32 rows each");
@@ -1825,8 +1932,9 @@ float DeviceIndex::gather_ceiling(uint32_t n_waves, uint32_t rows_per_wave, uint
     try {
         // (the same row-shape kernels the search uses)
         typedef void (*CeilingKernel)(DeviceGraph, uint32_t, float*);
-        const int nl = row_shape_loads(g.d);
-        const CeilingKernel ck = nl == 8 ? gather_ceiling_kernel<8> : (nl == 6 ? gather_ceiling_kernel<6> : gather_ceiling_kernel<0>);
+        const int nl = row_shape_loads(g.d, scalar);
+        const CeilingKernel ck = scalar ? (nl == 7 ? gather_ceiling_kernel<7, true> : gather_ceiling_kernel<0, true>)
+                                        : (nl == 8 ? gather_ceiling_kernel<8> : (nl == 6 ? gather_ceiling_kernel<6> : gather_ceiling_kernel<0>));
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ck), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
         HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
         hipLaunchKernelGGL(ck, dim3(n_waves), dim3(64), lds, stream, g, iters, d_out);       // warm-up
@@ -1844,7 +1952,7 @@ float DeviceIndex::gather_ceiling(uint32_t n_waves, uint32_t rows_per_wave, uint
     }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     HIP_CHECK(hipFree(d_out));
-    bytes = (uint64_t)n_waves * iters * 32u * (g.d & ~15u) * 4u;      // the bytes the search's counters would charge for these rows
+    bytes = (uint64_t)n_waves * iters * 32u * (scalar ? g.d : (g.d & ~15u)) * 4u;      // the bytes the search's counters would charge for these rows
     return ms / 3.0f;
 }
 

@@ -145,10 +145,11 @@ class HNSW:
         """The library reads its diagnostic environment switches when the index is copied to the GPU; read them again."""
         capi.check(capi.lib().hnsw_amd_reload_env(self._h))
 
-    def gather_ceiling(self, n_waves: int, rows_per_wave: int, lds_bytes_per_wave: int, stream: int = 0):
+    def gather_ceiling(self, n_waves: int, rows_per_wave: int, lds_bytes_per_wave: int, stream: int = 0, scalar: bool = False):
         """(ms, bytes) of one launch of the row-gather probe on this index's vector table (see include/hnsw_amd.h)."""
         ms, nbytes = C.c_float(0), C.c_uint64(0)
-        capi.check(capi.lib().hnsw_amd_gather_ceiling_device(self._h, n_waves, rows_per_wave, lds_bytes_per_wave, stream or None,
+        capi.check(capi.lib().hnsw_amd_gather_ceiling_device(self._h, n_waves, rows_per_wave, lds_bytes_per_wave,
+                                                             capi.DIST_SCALAR if scalar else capi.DIST_SSE, stream or None,
                                                              C.byref(ms), C.byref(nbytes)))
         return ms.value, nbytes.value
 

@@ -252,11 +252,12 @@ int hnsw_amd_get_info(hnsw_amd_index* h, int32_t* M, int32_t* Mmax, int32_t* Mma
  * reads when nothing else is in the way.  n_waves wavefronts each compute distances to rows_per_wave (a multiple of
  * 32) uniformly random rows of the index's own vector table with the search kernel's loads and arithmetic, but
  * without heaps, visited set, neighbour lists or any dependence between batches; lds_bytes_per_wave sets how many
- * wavefronts a CU holds, as the search's scratch does.  *ms = time of one launch, *bytes = what the search's
- * counters would charge for those rows (4 * 16*floor(d/16) each); bytes / ms is the ceiling a search on this
- * index can be compared with.  Waits for the stream. */
-int hnsw_amd_gather_ceiling_device(hnsw_amd_index* h, uint32_t n_waves, uint32_t rows_per_wave, uint32_t lds_bytes_per_wave, void* stream,
-                                   float* ms, uint64_t* bytes);
+ * wavefronts a CU holds, as the search's scratch does; dist_flag (HNSW_AMD_DIST_SSE / HNSW_AMD_DIST_SCALAR) picks the
+ * arithmetic.  *ms = time of one launch, *bytes = what the search's counters would charge for those rows
+ * (4 * 16*floor(d/16) each, or 4 * d in scalar order); bytes / ms is the ceiling a search on this index can be
+ * compared with.  Waits for the stream. */
+int hnsw_amd_gather_ceiling_device(hnsw_amd_index* h, uint32_t n_waves, uint32_t rows_per_wave, uint32_t lds_bytes_per_wave, uint32_t dist_flag,
+                                   void* stream, float* ms, uint64_t* bytes);
 
 /* Measurement aid, no counterpart in the reference: how the last search call's (first) launch was configured — on-chip
  * scratch (LDS) bytes per query, how many queries a CU holds at once with that (what bounds a latency-bound

@@ -22,6 +22,9 @@ ap.add_argument("--nq", type=int, default=10_000)
 ap.add_argument("--ef", type=int, default=50)
 ap.add_argument("--threads", type=int, default=16)
 ap.add_argument("--kind", default="sift")
+ap.add_argument("--dist", default="sse", choices=["sse", "scalar"])
+ap.add_argument("--keys", default="int32", choices=["int32", "float"])
+ap.add_argument("--cache", default="", help="npz of the flat graph (as tools/probe.py --cache writes it): load instead of building")
 ap.add_argument("--build-keys", default="int32", choices=["int32", "float"])
 ap.add_argument("--want-visit", type=int, default=0,
                 help="the diagnostic kernel reports no sizes, so the launcher cannot learn them: give the visited count to size for")
@@ -29,10 +32,17 @@ a = ap.parse_args()
 base = datagen.make(a.kind, a.n, seed=1)
 q = datagen.make(a.kind, a.nq, seed=1, stream=1)
 h = HNSW(16, 16, 200)
-h.init(base.shape[1], a.n)
-if a.build_keys == "float":
-    h.set_build_float_keys(True)
-t = time.time(); h.insert_batch(base, threads=a.threads); print(f"build {time.time()-t:.1f}s", flush=True)
+if a.cache and os.path.exists(a.cache):
+    from hnsw_amd.flatgraph import FlatGraph
+    h.import_flat(FlatGraph.from_npz(np.load(a.cache)), base)
+else:
+    h.init(base.shape[1], a.n)
+    if a.build_keys == "float":
+        h.set_build_float_keys(True)
+    h.set_build_distance(a.dist)
+    t = time.time(); h.insert_batch(base, threads=a.threads); print(f"build {time.time()-t:.1f}s", flush=True)
+from hnsw_amd import capi  # noqa: E402
+h.flags = (capi.DIST_SCALAR if a.dist == "scalar" else capi.DIST_SSE) | (capi.KEYS_FLOAT if a.keys == "float" else capi.KEYS_INT32)
 h.sync_device(0)
 if a.want_visit:
     os.environ["HNSW_AMD_WANT_VISIT"] = str(a.want_visit)

@@ -23,6 +23,7 @@ ap.add_argument("--kind", default="sift")
 ap.add_argument("--keys", default="int32")
 ap.add_argument("--rows", default="f32", choices=["f32", "u8"])
 ap.add_argument("--build-keys", default="int32", choices=["int32", "float"])
+ap.add_argument("--dist", default="sse", choices=["sse", "scalar"])
 a = ap.parse_args()
 bcache = (a.cache + ".base.npy") if a.cache else ""
 if bcache and os.path.exists(bcache):
@@ -39,6 +40,7 @@ else:
     h.init(base.shape[1], a.n)
     if a.build_keys == "float":
         h.set_build_float_keys(True)
+    h.set_build_distance(a.dist)
     t = time.time(); h.insert_batch(base, threads=a.threads); print(f"build {time.time()-t:.1f}s", flush=True)
     if a.cache:
         np.savez(a.cache, **h.export_flat().to_npz_dict())
@@ -48,12 +50,12 @@ for ef in [int(x) for x in a.ef.split(",")]:
   print(f"ef={ef}", flush=True)
   for rep in range(a.reps):
     t = time.time()
-    h.flags = capi.DIST_SSE | (capi.KEYS_FLOAT if a.keys == "float" else capi.KEYS_INT32) | (capi.ROWS_U8 if a.rows == "u8" else 0)
+    h.flags = (capi.DIST_SCALAR if a.dist == "scalar" else capi.DIST_SSE) | (capi.KEYS_FLOAT if a.keys == "float" else capi.KEYS_INT32) | (capi.ROWS_U8 if a.rows == "u8" else 0)
     ids, ds, cnt, st = h.search_batch(q, ef, out_k=10, stats=True)
     if rep == a.reps - 1:
         from hnsw_amd import harness
         d_ = base.shape[1]
-        print("algorithmic_bytes_per_launch", int(harness.algorithmic_bytes(st, d_, d_ & ~15, 10, 1 if a.rows == "u8" else 4).sum()),
+        print("algorithmic_bytes_per_launch", int(harness.algorithmic_bytes(st, d_, d_ if a.dist == "scalar" else d_ & ~15, 10, 1 if a.rows == "u8" else 4).sum()),
               "launch", h.last_launch_info(), flush=True)
     print(f"rep {rep}: host wall {1e3*(time.time()-t):.2f} ms", flush=True)
   print("n_dist/q", st["n_dist"].mean(), "expansions/q", st["n_expand"].mean())
