@@ -195,11 +195,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
                     bv[t] = *reinterpret_cast<const float4*>(&Bs[(wc * 64 + t * 32 + fi) * kLd + 8 * j + 4 * fk]);
                 }
             };
+            // (a row that ends inside this step: the groups of 8 k past its end hold nothing but zeros and are skipped,
+            // so d = 100 costs 13 groups, not 16)
+            const int nj = d - k0 >= (uint32_t)kBK ? kBK / 8 : (int)((d - k0 + 7u) >> 3);
             read_group(0, a, b);
 #pragma unroll
             for (int j = 0; j < kBK / 8; j++) {
+                if (j >= nj) break;
                 float4 an[2], bn[2];
-                if (j + 1 < kBK / 8) read_group(j + 1, an, bn);
+                if (j + 1 < nj) read_group(j + 1, an, bn);
                 __builtin_amdgcn_sched_barrier(0);          // (the scheduler would otherwise sink the reads to where their registers free up)
 #pragma unroll
                 for (int e = 0; e < 4; e++)
@@ -208,7 +212,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
 #pragma unroll
                         for (int tb = 0; tb < 2; tb++)
                             acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(el(a[ta], e), el(b[tb], e), acc[ta][tb], 0, 0, 0);
-                if (j + 1 < kBK / 8) {
+                if (j + 1 < nj) {
 #pragma unroll
                     for (int t = 0; t < 2; t++) { a[t] = an[t]; b[t] = bn[t]; }
                 }
