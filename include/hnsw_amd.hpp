@@ -239,6 +239,28 @@ public:
     {
         check(hnsw_amd_search_batch(h_, queries, nq, ef, out_k, search_flags, out_ids, out_dist, out_count, stats));
     }
+    // The batched search on buffers that are already in the GPU's memory, as one blocking call or in two halves (up to
+    // four batches in flight on one index; no counterpart in the reference, whose driver runs one blocking query at a time).
+    uint32_t searchBatchDevice(const float* d_queries, uint32_t nq, int ef, uint32_t out_k, uint32_t* d_ids, float* d_dist,
+                               uint32_t* d_count = nullptr, void* stream = nullptr)
+    {
+        uint32_t retried = 0;
+        check(hnsw_amd_search_batch_device(h_, d_queries, nq, ef, out_k, search_flags, d_ids, d_dist, d_count, nullptr, stream, &retried));
+        return retried;
+    }
+    hnsw_amd_search_call* searchBatchDeviceBegin(const float* d_queries, uint32_t nq, int ef, uint32_t out_k, uint32_t* d_ids,
+                                                 float* d_dist, uint32_t* d_count = nullptr, void* stream = nullptr)
+    {
+        hnsw_amd_search_call* call = nullptr;
+        check(hnsw_amd_search_batch_device_begin(h_, d_queries, nq, ef, out_k, search_flags, d_ids, d_dist, d_count, nullptr, stream, &call));
+        return call;
+    }
+    uint32_t searchBatchDeviceFinish(hnsw_amd_search_call* call)
+    {
+        uint32_t retried = 0;
+        check(hnsw_amd_search_batch_device_finish(h_, call, &retried));
+        return retried;
+    }
     void syncDevice(int device = 0) { check(hnsw_amd_sync_device(h_, device)); }
 
     // src/hnsw.cpp:1178-1240, 1244-1311: an unopenable file is reported and the call returns; any other failure is
