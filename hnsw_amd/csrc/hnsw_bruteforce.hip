@@ -79,7 +79,8 @@ struct EmitArgs {
 // the other (the blocks that share a column tile sit next to each other in launch order, so a tile of base rows is
 // fetched from memory about once and then served by the L2s), and asks for its next tile's first operands before it
 // turns to the distances of the current one.
-template <bool EMIT, bool VEC>
+// TAIL: the rows end inside a k step (d % 32 != 0): the groups of 8 k past the end of a row are skipped.
+template <bool EMIT, bool VEC, bool TAIL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void dist_tile_kernel(const float* __restrict__ Q, const float* __restrict__ X,
                                                         const float* __restrict__ qn, const float* __restrict__ xn,
                                                         uint32_t nq, uint32_t n, uint32_t d, uint32_t x0, uint32_t cw, uint32_t ntx,
@@ -197,13 +198,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
             };
             // (a row that ends inside this step: the groups of 8 k past its end hold nothing but zeros and are skipped,
             // so d = 100 costs 13 groups, not 16)
-            const int nj = d - k0 >= (uint32_t)kBK ? kBK / 8 : (int)((d - k0 + 7u) >> 3);
+            const int nj = (!TAIL || d - k0 >= (uint32_t)kBK) ? kBK / 8 : (int)((d - k0 + 7u) >> 3);
             read_group(0, a, b);
 #pragma unroll
             for (int j = 0; j < kBK / 8; j++) {
-                if (j >= nj) break;
+                if (TAIL && j >= nj) break;
                 float4 an[2], bn[2];
-                if (j + 1 < nj) read_group(j + 1, an, bn);
+                if (TAIL ? j + 1 < nj : j + 1 < kBK / 8) read_group(j + 1, an, bn);
                 __builtin_amdgcn_sched_barrier(0);          // (the scheduler would otherwise sink the reads to where their registers free up)
 #pragma unroll
                 for (int e = 0; e < 4; e++)
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
 #pragma unroll
                         for (int tb = 0; tb < 2; tb++)
                             acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(el(a[ta], e), el(b[tb], e), acc[ta][tb], 0, 0, 0);
-                if (j + 1 < nj) {
+                if (TAIL ? j + 1 < nj : j + 1 < kBK / 8) {
 #pragma unroll
                     for (int t = 0; t < 2; t++) { a[t] = an[t]; b[t] = bn[t]; }
                 }
@@ -387,6 +388,7 @@ float bruteforce_knn(const float* d_base, uint32_t n, const float* d_queries, ui
     hipStream_t stream = (hipStream_t)stream_v;
     const uint32_t kp = k + 8;                        // kept entries: a margin beyond k for the final re-scoring
     const bool vec = (d & 3u) == 0 && ((uintptr_t)d_base & 15u) == 0 && ((uintptr_t)d_queries & 15u) == 0;
+    const bool tail = (d % (uint32_t)kBK) != 0;      // rows end inside a k step
     constexpr uint32_t kCap = 1024;                   // candidate list per query and chunk
     // plain path: distance matrix of at most about 1 GiB at a time
     const uint32_t cw = (uint32_t)std::min<uint64_t>(n, std::max<uint64_t>(kBN, ((1ull << 28) / nq) / kBN * kBN));
@@ -441,7 +443,7 @@ float bruteforce_knn(const float* d_base, uint32_t n, const float* d_queries, ui
                 const uint32_t valid = std::min(cw, hi - x0);
                 timed([&] {
                     const uint32_t ntx = (valid + kBN - 1) / kBN;
-                    hipLaunchKernelGGL((vec ? dist_tile_kernel<false, true> : dist_tile_kernel<false, false>), dim3((nq + kBM - 1) / kBM, workers_for(ntx)), dim3(256), 0, stream,
+                    hipLaunchKernelGGL((tail ? (vec ? dist_tile_kernel<false, true, true> : dist_tile_kernel<false, false, true>) : (vec ? dist_tile_kernel<false, true, false> : dist_tile_kernel<false, false, false>)), dim3((nq + kBM - 1) / kBM, workers_for(ntx)), dim3(256), 0, stream,
                                        d_queries, d_base, qn, xn, nq, n, d, x0, cw, ntx, D, EmitArgs{});
                 });
                 hipLaunchKernelGGL(select_topk_kernel<false>, dim3(nq), dim3(64), pool_bytes, stream, D, cw, x0, id_offset, valid, kp, best_d,
@@ -462,7 +464,7 @@ float bruteforce_knn(const float* d_base, uint32_t n, const float* d_queries, ui
             const EmitArgs em{best_d, kp, cand, cnt, kCap, id_offset};
             timed([&] {
                 const uint32_t ntx = (width + kBN - 1) / kBN;
-                hipLaunchKernelGGL((vec ? dist_tile_kernel<true, true> : dist_tile_kernel<true, false>), dim3((nq + kBM - 1) / kBM, workers_for(ntx)), dim3(256), 0, stream,
+                hipLaunchKernelGGL((tail ? (vec ? dist_tile_kernel<true, true, true> : dist_tile_kernel<true, false, true>) : (vec ? dist_tile_kernel<true, true, false> : dist_tile_kernel<true, false, false>)), dim3((nq + kBM - 1) / kBM, workers_for(ntx)), dim3(256), 0, stream,
                                    d_queries, d_base, qn, xn, nq, n, d, seen, width, ntx, (float*)nullptr, em);
             });
             hipLaunchKernelGGL(select_topk_kernel<true>, dim3(nq), dim3(64), pool_bytes, stream, (const float*)nullptr, 0u, 0u, id_offset, 0u, kp,

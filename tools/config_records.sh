@@ -11,8 +11,15 @@ a)
   run sift128_1m_rows_u8 --rows u8 &&
   run fmnist784_60k --kind fmnist --base-size 60000 --ef 64 &&
   run fmnist784_60k_rows_u8 --kind fmnist --base-size 60000 --ef 64 --rows u8 --cpu-baseline none &&
-  run glove100_1.18M_scalar_int32_sweep --kind glove --base-size 1183514 --dist scalar --sweep 10,20,30,40,60,80,100,150,200 --cpu-baseline none &&
-  run glove100_1.18M_scalar_float_sweep --kind glove --base-size 1183514 --dist scalar --keys float --sweep 10,20,30,40,60,80,100,150,200,300 --cpu-baseline none
+  run glove100_1.18M_scalar_int32_sweep --kind glove --base-size 1183514 --dist scalar --build gpu --sweep 10,20,30,40,60,80,100,150,200 --cpu-baseline none &&
+  run glove100_1.18M_scalar_float_sweep --kind glove --base-size 1183514 --dist scalar --build gpu --keys float --sweep 10,20,30,40,60,80,100,150,200,300 --cpu-baseline none
+  ;;
+g)
+  # the GloVe-shaped configuration as full bench lines (operating point, roofline with the scalar-order gather ceiling, CPU baseline =
+  # the reference's scalar build where its visited table survives the queries): index built AND searched with the scalar distance
+  export HNSW_AMD_BENCH_CACHE=/tmp/bcache; mkdir -p /tmp/bcache
+  run glove100_1.18M_scalar_int32 --kind glove --base-size 1183514 --dist scalar --build gpu --target-recall 0.95 &&
+  run glove100_1.18M_scalar_float --kind glove --base-size 1183514 --dist scalar --build gpu --keys float --target-recall 0.95 --cpu-baseline port
   ;;
 b)
   run gist960_1m --kind gist --base-size 1000000 --queries 1000 --cpu-baseline none &&
