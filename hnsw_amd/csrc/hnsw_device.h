@@ -169,7 +169,6 @@ private:
     void set_max_dynamic_lds(const void* kernel, size_t lds);
     SearchCall calls_[kMaxCallsInFlight];
     SearchCall noalloc_call_;          // the entry point that allocates nothing: lists in the library's static device array
-    std::vector<std::pair<const void*, size_t>> func_lds_;    // largest dynamic LDS size each kernel was enabled for
     void* bufs_[8] = {};
 };
 

@@ -1841,7 +1841,6 @@ void DeviceIndex::upload(const HostIndex& h, int dev)
     if (!noalloc_call_.h_report) HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&noalloc_call_.h_report), 64, hipHostMallocDefault));
     (void)noalloc_scratch_for(dev, true);
     tune.read();
-    func_lds_.clear();
     dot4_off = false; pack_off = false;
     version = h.version_;
     rows_epoch = h.rows_epoch_;
@@ -2105,17 +2104,23 @@ void Tunables::read()
     lds_pad = num("HNSW_AMD_LDS_PAD", 0);            // occupancy experiments
 }
 
+// The largest dynamic LDS size a kernel was enabled for is a property of the process (per device and kernel), not of an
+// index: the table is shared by every index, and the size is only ever raised.
 void DeviceIndex::set_max_dynamic_lds(const void* kern, size_t lds)
 {
     if (lds <= 32768) return;
-    for (auto& f : func_lds_) if (f.first == kern) {
-        if (f.second >= lds) return;
+    struct Enabled { int device; const void* kernel; size_t bytes; };
+    static std::vector<Enabled> table;
+    static std::mutex table_mutex;
+    std::lock_guard<std::mutex> lock(table_mutex);
+    for (Enabled& e : table) if (e.device == device && e.kernel == kern) {
+        if (e.bytes >= lds) return;
         HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        f.second = lds;
+        e.bytes = lds;
         return;
     }
     HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    func_lds_.emplace_back(kern, lds);
+    table.push_back({device, kern, lds});
 }
 
 // ---- one search call = begin (size the scratch from what is known, launch, queue the report) + finish (wait for the
