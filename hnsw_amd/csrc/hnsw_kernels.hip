@@ -510,15 +510,18 @@ __device__ __forceinline__ void issue_item(const float* p, uint32_t nld, float4 
 }
 
 // A kernel built for one row shape keeps the lane's pieces of the query in registers for the whole search (all six
-// of a 96-dim row; the first four of a 128-dim row, whose kernels have less room), so that a distance batch does not
+// of a 96-dim row; the first two of a 128-dim row, whose kernels have less room), so that a distance batch does not
 // wait for them to come out of LDS piece by piece.
 // (Byte rows of 128 dims: all eight pieces, in the byte rows' own order of the query copy; those kernels have the room.)
+#ifndef HNSW_QK8
+#define HNSW_QK8 2       // pieces of a 128-dim float query a lane keeps in registers (0, 2 and 4 measure within 1 %; 8 spills in the bucket-form kernels)
+#endif
 // RK: 0 = float rows, 1 = byte rows read through the float arithmetic, 2 = byte rows through integer dot products (the
 // lane's 32 bytes of each 128-dim block of the query as packed bytes, plus the query's squared norm).
 template <int NL, int RK = 0>
 struct QRegs {
     // (the scalar-order kernels, NL = 7, read the query from LDS)
-    static constexpr int K = RK == 2 ? 0 : (RK != 0 ? (NL == 8 ? 8 : 0) : (NL == 6 ? 6 : (NL == 8 ? 4 : 0)));
+    static constexpr int K = RK == 2 ? 0 : (RK != 0 ? (NL == 8 ? 8 : 0) : (NL == 6 ? 6 : (NL == 8 ? HNSW_QK8 : 0)));
     float4 q[K ? K : 1];
     static constexpr int KB = RK == 2 && NL == 8 ? 2 : 0;
     uint4 qb[KB ? KB : 1];
@@ -1999,7 +2002,7 @@ static SearchKernel pick_rows(bool scalar, int wr, int rows, bool ip, int nl, in
     if (rows == 2 && nl == 8) return pick_wr<false, 2, BUCKET, 2, false, 8>(wr);
     if (rows == 1) return pick_wr<false, 1, BUCKET, 2>(wr);
     if (rows == 2) return pick_wr<false, 2, BUCKET, 2>(wr);
-    if (nl == 8) return pick_wr<false, 0, BUCKET, 2, false, 8>(wr, 4, packc);
+    if (nl == 8) return pick_wr<false, 0, BUCKET, 2, false, 8>(wr, wps, packc);
     if (nl == 6) return pick_wr<false, 0, BUCKET, 2, false, 6>(wr, 4, packc);
     return pick_wr<false, 0, BUCKET, 2>(wr, 4, packc);
 }
@@ -2093,7 +2096,8 @@ void Tunables::read()
     no_spill = on("HNSW_AMD_NO_SPILL");              // bucket form without spill tables
     verbose = on("HNSW_AMD_VERBOSE");                // launch configuration and kernel times on stderr
     no_pack_c = on("HNSW_AMD_NO_PACK_C");            // candidate heap entries of 8 bytes even where 4 would do
-    no_dot4 = on("HNSW_AMD_NO_DOT4");                // byte rows through the float arithmetic even where integer dot products are exact
+    no_dot4 = on("HNSW_AMD_NO_DOT4");
+    force_wps5 = on("HNSW_AMD_WPS5");                // experiment: 20 queries per CU for float rows of 128 dims, ef <= 64                // byte rows through the float arithmetic even where integer dot products are exact
     const char* bf = getenv("HNSW_AMD_BULK_FRAC");
     bulk_frac = bf ? (float)atof(bf) : 0.30f;        // (0.45 and 0.30 measure alike on the SIFT-shaped set; 0.30 lets the 12.5 M-row DEEP-shaped shard hold more queries per CU)
     want_visit = num("HNSW_AMD_WANT_VISIT", -1);     // a fixed size of the visited set
