@@ -2097,7 +2097,6 @@ void Tunables::read()
     verbose = on("HNSW_AMD_VERBOSE");                // launch configuration and kernel times on stderr
     no_pack_c = on("HNSW_AMD_NO_PACK_C");            // candidate heap entries of 8 bytes even where 4 would do
     no_dot4 = on("HNSW_AMD_NO_DOT4");
-    force_wps5 = on("HNSW_AMD_WPS5");                // experiment: 20 queries per CU for float rows of 128 dims, ef <= 64                // byte rows through the float arithmetic even where integer dot products are exact
     const char* bf = getenv("HNSW_AMD_BULK_FRAC");
     bulk_frac = bf ? (float)atof(bf) : 0.30f;        // (0.45 and 0.30 measure alike on the SIFT-shaped set; 0.30 lets the 12.5 M-row DEEP-shaped shard hold more queries per CU)
     want_visit = num("HNSW_AMD_WANT_VISIT", -1);     // a fixed size of the visited set
