@@ -78,6 +78,9 @@ struct SearchCall {
     uint32_t* d_lists = nullptr;      // two lists of list_cap words each: kFailHeader words of header, then query indices
     uint32_t list_cap = 0;
     uint32_t* h_report = nullptr;     // pinned host mirror of a list's header
+    uint32_t* h_report_dev = nullptr; // the same memory as the GPU addresses it
+    bool headers_zero = false;        // both list headers are known to be zero (every launch leaves them so)
+    bool* headers_zero_flag = nullptr; // that flag, or the one of the library's static array (the entry point that allocates nothing)
     uint32_t* d_spill = nullptr;      // pool of spill tables (bucket form of the visited set), allocated on first need
     // the call
     SearchArgs a{};

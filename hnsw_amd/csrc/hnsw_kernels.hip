@@ -61,6 +61,7 @@ namespace {
 // index is first uploaded to that GPU, with that GPU current.
 constexpr int kMaxDevices = 64;
 uint32_t* g_noalloc_scratch[kMaxDevices] = {};
+bool g_noalloc_headers_zero[kMaxDevices] = {};      // both list headers in the array are known to be zero (every launch leaves them so)
 std::mutex g_noalloc_mutex;
 
 uint32_t* noalloc_scratch_for(int dev, bool lookup)
@@ -1658,6 +1659,22 @@ __global__ __launch_bounds__(64) void gather_ceiling_kernel(DeviceGraph g, uint3
     if (lane == 0) out[blockIdx.x] = acc;
 }
 
+// The end of a launch: its report (the header of its overflow list) goes to the host, and the header is cleared for the
+// next launch that uses the list.  `host_words` is pinned host memory the host is watching: the first seven words are
+// written, then — after a system-wide fence — the eighth, whose arrival tells the host that the others are there.
+// One small dispatch behind the search kernel on the same stream; it replaces a clear in front of the launch and a
+// copy engine's transfer behind it.
+__global__ __launch_bounds__(64) void report_kernel(uint32_t* __restrict__ header, uint32_t* __restrict__ host_words)
+{
+    const uint32_t i = threadIdx.x;
+    uint32_t v = 0;
+    if (i < kFailHeader) v = header[i];
+    if (i + 1 < kFailHeader) __hip_atomic_store(&host_words[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    if (i < kFailHeader) header[i] = 0u;
+    if (i + 1 == kFailHeader) __hip_atomic_store(&host_words[i], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // Rows as the caller has them (n x d, dense) -> stored form (n x row_stride, regrouped lines, zero padded).
 __global__ void store_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, uint32_t rows, uint32_t d, uint32_t row_stride)
 {
@@ -1758,6 +1775,7 @@ void DeviceIndex::release()
     for (SearchCall& c : calls_) drop(c);
     noalloc_call_.d_spill = nullptr;          // (borrowed, never owned)
     drop(noalloc_call_);
+    if (device >= 0 && device < kMaxDevices) g_noalloc_headers_zero[device] = false;      // (be sure rather than remember)
     version = ~0ull; rows_epoch = 0;
 }
 
@@ -2173,11 +2191,15 @@ SearchCall* DeviceIndex::begin(const float* d_queries, uint32_t nq, int ef, uint
             c.d_lists = nullptr; c.list_cap = 0;
             HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&c.d_lists), ((size_t)nq + kFailHeader) * 4 * 2));
             c.list_cap = nq + kFailHeader;
+            c.headers_zero = false;
         }
         if (!c.h_report) HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&c.h_report), 64, hipHostMallocDefault));
         c.cur = c.d_lists;
         c.other = c.d_lists + c.list_cap;
+        c.headers_zero_flag = &c.headers_zero;
     }
+    if (no_alloc) c.headers_zero_flag = &g_noalloc_headers_zero[device];
+    if (!c.h_report_dev) HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&c.h_report_dev), c.h_report, 0));
 
     SearchArgs& a = c.a;
     a = SearchArgs{};
@@ -2407,7 +2429,13 @@ void DeviceIndex::launch_tier(SearchCall& c)
         if (lds > (size_t)max_lds) throw std::length_error("search: the query's scratch and the two-wavefront mailbox do not fit the LDS");
     }
     a.fail_count = c.cur; a.fail_list = c.cur + kFailHeader;
-    HIP_CHECK(hipMemsetAsync(c.cur, 0, 4 * kFailHeader, stream));
+    // The headers of both lists are zero between launches: each launch's report kernel clears the one it used.  Only a
+    // list that is new, or whose last launch did not get as far as its report, is cleared here.
+    if (!*c.headers_zero_flag) {
+        HIP_CHECK(hipMemsetAsync(c.cur, 0, 4 * kFailHeader, stream));
+        HIP_CHECK(hipMemsetAsync(c.other, 0, 4 * kFailHeader, stream));
+    }
+    *c.headers_zero_flag = false;
     // The report's words are preset to all ones on the host; the device's copy holds zero in the last word (cleared
     // with the rest of the header, never written by the kernel) and counts that cannot be all ones in the others.
     for (uint32_t w = 0; w < kFailHeader; w++) c.h_report[w] = 0xFFFFFFFFu;
@@ -2437,17 +2465,18 @@ void DeviceIndex::launch_tier(SearchCall& c)
     if (tier == 0) { last_kernel = reinterpret_cast<const void*>(kern); last_lds = (uint32_t)lds; last_block = block_threads; last_wps = wps; last_form = a.vis_rb == 0xFFFFFFFFu ? 0 : (a.vis_chunks ? 2 : 1); }
     if (c.timed) HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(c.ev1), stream));
     if (c.has_copy_back) HIP_CHECK(hipMemcpyAsync(c.copy_back.dst, c.copy_back.src, c.copy_back.bytes, hipMemcpyDeviceToHost, stream));
-    HIP_CHECK(hipMemcpyAsync(c.h_report, c.cur, 4 * kFailHeader, hipMemcpyDeviceToHost, stream));
+    hipLaunchKernelGGL(report_kernel, dim3(1), dim3(64), 0, stream, c.cur, c.h_report_dev);
+    HIP_CHECK(hipGetLastError());
     c.launched = true;
 }
 
-// The launch's report travels to a pinned host buffer, and the host waits by watching it: no stream synchronisation (the
-// caller's stream is often the legacy default stream, whose synchronisation also covers whatever other threads of the
-// process keep adding to it or to streams it synchronises with), no event, nothing to wake up — measured 20 us per call
-// less than an event wait, which is 4 % of a 10 000-query batch at ef=20.  The wait spins for the length of an ordinary
-// batch, then yields the core between looks, then sleeps between them; the stream is queried now and then so that an
-// error ends the wait.  Every word read afterwards is itself waited for (all were preset to a value the device never
-// sends), so nothing depends on the order in which the words of the copy land.
+// The launch's report is written into a pinned host buffer by a one-wavefront kernel queued behind the search kernel
+// (report_kernel), and the host waits by watching that buffer: no stream synchronisation (the caller's stream is often the
+// legacy default stream, whose synchronisation also covers whatever other threads of the process keep adding to it or to
+// streams it synchronises with), no event, no copy engine, nothing to wake up — measured 20 us per call less than an event
+// wait.  The wait spins for the length of an ordinary batch, then yields the core between looks, then sleeps between them;
+// the stream is queried now and then so that an error ends the wait.  Every word read afterwards is itself waited for (all
+// were preset to a value the device never sends), so nothing depends on the order in which the words land.
 void DeviceIndex::wait_report(SearchCall& c)
 {
     hipStream_t stream = reinterpret_cast<hipStream_t>(c.stream);
@@ -2473,6 +2502,7 @@ void DeviceIndex::wait_report(SearchCall& c)
         }
     }
     std::atomic_thread_fence(std::memory_order_acquire);
+    *c.headers_zero_flag = true;       // (the report kernel cleared the header it sent)
 }
 
 uint32_t DeviceIndex::finish(SearchCall* cp)
