@@ -249,16 +249,28 @@ int hnsw_amd_search_batch(hnsw_amd_index* h, const float* queries, uint32_t nq, 
             h->d_out = h->h_out = nullptr; h->out_bytes = 0;
             HIP_OK(hipMalloc(&h->d_out, ob)); HIP_OK(hipHostMalloc(&h->h_out, ob, hipHostMallocDefault)); h->out_bytes = ob;
         }
-        uint32_t* d_ids = static_cast<uint32_t*>(h->d_out);
+        std::memcpy(h->h_q, queries, qb);
+        // A handful of queries (the reference's own loop is one query per call, src/main.cpp:291-294): the kernel reads them
+        // from, and writes its results to, the pinned host buffers themselves — two copy-engine transfers less per call,
+        // which is most of what such a call costs besides the search.  Larger batches are staged through device memory.
+        const bool direct = nq <= 16;
+        void* q_src = h->d_q;
+        void* out_dst = h->d_out;
+        if (direct) {
+            HIP_OK(hipHostGetDevicePointer(&q_src, h->h_q, 0));
+            HIP_OK(hipHostGetDevicePointer(&out_dst, h->h_out, 0));
+        } else {
+            HIP_OK(hipMemcpyAsync(h->d_q, h->h_q, qb, hipMemcpyHostToDevice, nullptr));
+        }
+        uint32_t* d_ids = static_cast<uint32_t*>(out_dst);
         float* d_dist = reinterpret_cast<float*>(d_ids + oe);
         uint32_t* d_cnt = d_ids + 2 * oe;
         hnsw_amd_query_stats* d_stats = reinterpret_cast<hnsw_amd_query_stats*>(d_cnt + nq);
-        std::memcpy(h->h_q, queries, qb);
-        HIP_OK(hipMemcpyAsync(h->d_q, h->h_q, qb, hipMemcpyHostToDevice, nullptr));
         // the results travel back behind every launch of the call, ahead of the wait that learns whether a launch
         // has to be repeated for some queries (rare); the last copy is the one that counts
         const DeviceIndex::CopyBack back{h->h_out, h->d_out, stats ? ob : ob - (size_t)nq * sizeof(hnsw_amd_query_stats)};
-        h->dev.search((const float*)h->d_q, nq, ef, out_k, flags, d_ids, d_dist, d_cnt, stats ? d_stats : nullptr, nullptr, false, &back);
+        h->dev.search((const float*)q_src, nq, ef, out_k, flags, d_ids, d_dist, d_cnt, stats ? d_stats : nullptr, nullptr, false,
+                      direct ? nullptr : &back);
         const uint32_t* r = static_cast<const uint32_t*>(h->h_out);
         std::memcpy(out_ids, r, oe * 4);
         std::memcpy(out_dist, r + oe, oe * 4);
