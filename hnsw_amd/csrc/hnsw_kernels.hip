@@ -1875,6 +1875,7 @@ void DeviceIndex::upload(const HostIndex& h, int dev)
 void DeviceIndex::refresh_graph(const HostIndex& h)
 {
     if (device < 0 || !g.vectors) throw std::logic_error("refresh_graph: index not on a device");
+    if (calls_in_flight()) throw std::logic_error("the index was changed while a search call on it was in flight: finish the call first");
     HIP_CHECK(hipSetDevice(device));
     FlatGraph fg;
     h.export_flat(fg, false);
