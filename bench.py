@@ -61,21 +61,21 @@ def main():
                          "--queries queries and no collective in the data path (work grows with N)")
     ap.add_argument("--no-alongside", action="store_true",
                     help="N > 1, sharded mode: skip the replicated-index measurement reported next to the sharded one")
-    ap.add_argument("--build", default="host", choices=["host", "gpu"],
+    ap.add_argument("--build", default="host", choices=["host", "gpu", "device"],
                     help="host: concurrent build on the host's cores; gpu: the construction searches on the GPU (a few times faster; "
-                         "same construction rule, slightly different graph)")
+                         "same construction rule, slightly different graph); device: selection and linking of layer 0 on the GPU as well")
     ap.add_argument("--build-keys", default="int32", choices=["int32", "float"],
                     help="float: the construction searches use float candidate keys (a regular HNSW graph, not the reference's; "
                          "several times faster to build on unit-norm data)")
     ap.add_argument("--sweep", default="", help="comma-separated ef values: report recall and QPS for each instead of one operating point")
     ap.add_argument("--preset", default="", choices=["", "sift1m", "deep100m"],
                     help="a named configuration: sift1m = the defaults; deep100m = DEEP-96-shaped 100M base split over the ranks "
-                         "(--gpus 8: 12.5M rows per GPU), GPU-assisted build with float construction keys, reference int32 search keys, "
+                         "(--gpus 8: 12.5M rows per GPU), build with layer 0 searched and linked on the GPU, float construction keys, reference int32 search keys, "
                          "no replicated leg.  --base-size after the preset scales it down for rehearsals")
     args = ap.parse_args()
     if args.preset == "deep100m":
         defaults = ap.parse_args([])
-        for name, value in (("kind", "deep"), ("n", 100_000_000), ("build", "gpu"), ("build_keys", "float"), ("no_alongside", True),
+        for name, value in (("kind", "deep"), ("n", 100_000_000), ("build", "device"), ("build_keys", "float"), ("no_alongside", True),
                             ("cpu_baseline", "none")):
             if getattr(args, name) == getattr(defaults, name):      # (an explicit flag wins over the preset)
                 setattr(args, name, value)
@@ -128,7 +128,7 @@ def main():
     # ---- build (host, concurrent inserts) or load from the cache directory ----
     h = HNSW(16, 16, 200, device=local_rank)
     cache = os.environ.get("HNSW_AMD_BENCH_CACHE")
-    cpath = os.path.join(cache, f"{args.kind}_n{args.n}_s{parts}_r{prank}{'_fk' if args.build_keys == 'float' else ''}{'_gb' if args.build == 'gpu' else ''}{'_sc' if args.dist == 'scalar' else ''}.npz") if cache else None
+    cpath = os.path.join(cache, f"{args.kind}_n{args.n}_s{parts}_r{prank}{'_fk' if args.build_keys == 'float' else ''}{'_gb' if args.build == 'gpu' else ('_dl' if args.build == 'device' else '')}{'_sc' if args.dist == 'scalar' else ''}.npz") if cache else None
     t0 = time.time()
     if cpath and os.path.exists(cpath):
         from hnsw_amd.flatgraph import FlatGraph
@@ -139,9 +139,11 @@ def main():
         if args.build_keys == "float":
             h.set_build_float_keys(True)
         h.set_build_distance(args.dist)           # the same reference build for insert() and for the search
-        step_rows = 500_000       # in pieces, so a long build keeps reporting progress
+        # in pieces, so a long build keeps reporting progress (larger ones when layer 0 lives on the device: every call
+        # hands it over and takes it back)
+        step_rows = 2_500_000 if args.build == "device" else 500_000
         for r0 in range(0, hi - lo, step_rows):
-            h.insert_batch(base[r0:r0 + step_rows], threads=args.build_threads, gpu=(args.build == "gpu"))
+            h.insert_batch(base[r0:r0 + step_rows], threads=args.build_threads, gpu=("link" if args.build == "device" else args.build == "gpu"))
             if hi - lo > step_rows:
                 log(f"rank {rank}: inserted {min(hi - lo, r0 + step_rows)} / {hi - lo} in {time.time() - t0:.0f}s")
         log(f"rank {rank}: built {hi - lo} vectors with {args.build_threads} threads in {time.time() - t0:.1f}s")

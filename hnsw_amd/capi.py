@@ -47,6 +47,7 @@ SYMBOLS = {
     "hnsw_amd_insert": (C.c_int, [C.c_void_p, _f32p]),
     "hnsw_amd_insert_batch": (C.c_int, [C.c_void_p, _f32p, C.c_uint32, C.c_int]),
     "hnsw_amd_insert_batch_assisted": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int]),
+    "hnsw_amd_insert_batch_linked": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int]),
     "hnsw_amd_set_build_float_keys": (C.c_int, [C.c_void_p, C.c_int]),
     "hnsw_amd_set_build_distance": (C.c_int, [C.c_void_p, C.c_uint32]),
     "hnsw_amd_aproximate_knn": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_uint32, _u32p, _f32p, _u32p]),

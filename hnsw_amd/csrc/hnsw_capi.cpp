@@ -27,6 +27,7 @@ void merge_topk(const float* d_dist, const uint32_t* d_ids, const uint32_t* shar
 struct hnsw_amd_index {
     HostIndex host;
     DeviceIndex dev;
+    DeviceBuild build;       // layer 0 of a device-linked build, while one runs
     int device = 0;
     FlatGraph exported;
     // grow-only staging of the host-pointer search entry points: queries and the packed results
@@ -94,6 +95,7 @@ void hnsw_amd_destroy(hnsw_amd_index* h)
 {
     if (!h) return;
     if (h->dev.device >= 0) (void)hipSetDevice(h->dev.device);
+    h->build.release();
     for (void* p : {h->d_q, h->d_out}) if (p) (void)hipFree(p);
     for (void* p : {h->h_q, h->h_out}) if (p) (void)hipHostFree(p);
     delete h;
@@ -142,6 +144,63 @@ int hnsw_amd_insert_batch_assisted(hnsw_amd_index* h, const float* rows, uint32_
         h->host.insert_batch(rows, n, threads, assisted_candidates, h);
         // the device holds every row already: bring its graph to the final state instead of leaving a full upload to
         // the first search
+        if (device_has_rows(h) && h->dev.version != h->host.version_) h->dev.refresh_graph(h->host);
+    });
+}
+
+// Layer 0 of the build on the device (hnsw_build.hip): the three callbacks of HostIndex::Layer0Linker.
+static uint32_t build_flags(const hnsw_amd_index* h)
+{
+    return (h->host.dist_scalar_ ? HNSW_AMD_DIST_SCALAR : HNSW_AMD_DIST_SSE) | (h->host.build_float_keys_ ? HNSW_AMD_KEYS_FLOAT : HNSW_AMD_KEYS_INT32);
+}
+
+static void linked_from_host(void* ctx)
+{
+    hnsw_amd_index* h = static_cast<hnsw_amd_index*>(ctx);
+    if (device_has_rows(h)) h->dev.refresh_graph(h->host);
+    else h->dev.upload(h->host, h->device);
+    h->build.from_host(h->dev, h->host);
+}
+
+static void linked_upper_layers(void* ctx)
+{
+    hnsw_amd_index* h = static_cast<hnsw_amd_index*>(ctx);
+    FlatGraph upper;
+    h->dev.refresh_graph(h->host, false, &upper);
+    h->build.upper_view(h->dev, upper);
+}
+
+static void linked_step(void* ctx, uint32_t first_id, uint32_t cnt, const uint32_t* upper_ids, uint32_t n_upper,
+                        uint32_t* cand_ids, float* cand_dist, uint32_t* cand_cnt)
+{
+    hnsw_amd_index* h = static_cast<hnsw_amd_index*>(ctx);
+    h->build.step(h->dev, h->host, first_id, cnt, build_flags(h), upper_ids, n_upper, cand_ids, cand_dist, cand_cnt);
+}
+
+static void linked_to_host(void* ctx)
+{
+    hnsw_amd_index* h = static_cast<hnsw_amd_index*>(ctx);
+    h->build.to_host(h->dev, h->host);
+}
+
+int hnsw_amd_insert_batch_linked(hnsw_amd_index* h, const float* rows, uint32_t n, int threads, int device)
+{
+    if (h && !DeviceBuild::supports(h->host)) return hnsw_amd_insert_batch_assisted(h, rows, n, threads, device);
+    return guarded([&] {
+        REQUIRE(h && (rows || n == 0), "insert_batch_linked: NULL argument");
+        int count = 0;
+        HIP_OK(hipGetDeviceCount(&count));
+        REQUIRE(device >= 0 && device < count, "insert_batch_linked: no such GPU");
+        h->device = device;
+        const HostIndex::Layer0Linker linker{h, linked_from_host, linked_upper_layers, linked_step, linked_to_host};
+        try {
+            h->host.insert_batch(rows, n, threads, nullptr, nullptr, &linker);
+        } catch (...) {
+            h->build.release();
+            throw;
+        }
+        h->build.release();
+        // the device holds every row and layer 0 already: upper layers and entry points to their final state
         if (device_has_rows(h) && h->dev.version != h->host.version_) h->dev.refresh_graph(h->host);
     });
 }

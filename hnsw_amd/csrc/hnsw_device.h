@@ -135,7 +135,14 @@ public:
     void release();
     void upload(const HostIndex& h, int device);
     // Builds the quantised byte table (HNSW_AMD_ROWS_Q8) on first use.
-    void refresh_graph(const HostIndex& h);      // lists and upper layers again; vectors stay (same rows)
+    // lists and upper layers again (or the upper layers only); vectors stay (same rows).  `exported`: the flat form of the
+    // upper layers it was made from, for a caller that needs it as well
+    void refresh_graph(const HostIndex& h, bool with_layer0 = true, FlatGraph* exported = nullptr);
+    // The blocking search on another graph over the same vectors (a build's view of an upper layer as a graph of its own):
+    // what batches on the view teach about scratch sizes is kept apart from the index's own (kFlagView in the flags).
+    static constexpr uint32_t kFlagView = 0x40000000u;
+    uint32_t search_on(const DeviceGraph& view, const float* d_queries, uint32_t nq, int ef, uint32_t out_k, uint32_t flags,
+                       uint32_t* d_ids, float* d_dist, uint32_t* d_count, void* stream);
     void ensure_quantized(const HostIndex& h);
     // Runs the batch (device pointers), re-running overflowed queries on larger tiers.
     // Returns the number of re-run queries; throws on HIP errors / scratch exhaustion.
@@ -173,6 +180,37 @@ private:
     SearchCall calls_[kMaxCallsInFlight];
     SearchCall noalloc_call_;          // the entry point that allocates nothing: lists in the library's static device array
     void* bufs_[8] = {};
+};
+
+// Layer 0 of a GPU-assisted build that is selected and linked on the device (hnsw_build.hip): the edge distances next
+// to the index's own device copy of the lists, and the buffers a sub-batch passes through.
+struct DeviceBuild {
+    float* dist0 = nullptr; size_t dist0_words = 0;          // n x deg0, beside DeviceGraph::adj0
+    float* d_q = nullptr; size_t q_words = 0;                // the sub-batch's rows as queries
+    uint32_t* d_cids = nullptr; size_t cand_words = 0;       // their candidate lists (ids, distances, lengths)
+    float* d_cdist = nullptr; size_t cdist_words = 0;
+    uint32_t* d_ccnt = nullptr; size_t ccnt_words = 0;
+    uint64_t *d_keys = nullptr, *d_keys2 = nullptr; size_t keys_words = 0, keys2_words = 0;   // (neighbour << 32 | new vector), unsorted / sorted
+    float *d_vals = nullptr, *d_vals2 = nullptr; size_t vals_words = 0, vals2_words = 0;      // the distance of each such link
+    void* d_tmp = nullptr; size_t tmp_bytes = 0;             // the sort's work space
+    // Layer 1 as a graph of its own over the same vectors (lists by node_order), with the layers above it: what the
+    // construction searches of vectors that live in layer 1 run on.  Rebuilt from the host's upper layers before every step.
+    uint32_t* adj1 = nullptr; size_t adj1_words = 0;         // n x degu, 0xFFFFFFFF where a vector has no layer-1 list
+    uint32_t* d_order1 = nullptr; size_t order1_words = 0;   // node_order of every layer-1 slot
+    uint32_t* v_up_off = nullptr; size_t v_up_off_words = 0;
+    uint32_t* v_up_down = nullptr; size_t v_up_down_words = 0;
+    DeviceGraph view{};
+    bool view_ok = false;
+    static bool supports(const HostIndex& h);                // list lengths and efConstruction the kernels are built for
+    void release();
+    void from_host(DeviceIndex& dev, const HostIndex& h);    // dist0 <- the host's edge distances
+    void upper_view(DeviceIndex& dev, const FlatGraph& upper);   // the view of layer 1, from the upper layers just put on the device
+    // vectors first_id .. first_id + cnt - 1 (added to the layers, not linked): search, select, link in layer 0; for those
+    // among them that live in layer 1 (upper_ids, n_upper of them) the candidate lists of their layer-1 search
+    // (ef = efConstruction entries each at cand_ids / cand_dist, lengths in cand_cnt; 0 = none, search on the host)
+    void step(DeviceIndex& dev, const HostIndex& h, uint32_t first_id, uint32_t cnt, uint32_t flags,
+              const uint32_t* upper_ids, uint32_t n_upper, uint32_t* cand_ids, float* cand_dist, uint32_t* cand_cnt);
+    void to_host(const DeviceIndex& dev, HostIndex& h);      // layer 0's lists, distances and counts into the host's arrays
 };
 
 }  // namespace hnsw_amd

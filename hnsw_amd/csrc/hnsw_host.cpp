@@ -376,8 +376,10 @@ void HostIndex::link(int layer, uint32_t new_slot, uint32_t id, const std::vecto
 // path only): the slot reserved for this vector in each layer 0..min(level, top).
 template <bool MT>
 void HostIndex::insert_one(uint32_t id, const float* q, int level, const uint32_t* new_slots, Scratch& s,
-                           const uint32_t* cand_ids, const float* cand_dist, uint32_t cand_cnt)
+                           const uint32_t* cand_ids, const float* cand_dist, uint32_t cand_cnt, bool upper_layers_only, const uint32_t* slot1_of)
 {
+    // the layer whose candidate list comes from outside: 0, or 1 when layer 0 is not this function's business at all
+    const int cand_layer = upper_layers_only ? 1 : 0;
     const int L = (int)layers_.size() - 1;
     s.reset_visited((size_t)max_node_count_);
     s.W.clear();
@@ -393,7 +395,8 @@ void HostIndex::insert_one(uint32_t id, const float* q, int level, const uint32_
     }
     uint32_t prev_slot = kPad; int prev_layer = -1;
     uint32_t top_new_slot = kPad;     // the reference's down_node
-    for (int i = std::min(L, level); i >= 0; i--) {
+    // (upper_layers_only: layer 0 is searched and linked elsewhere)
+    for (int i = std::min(L, level); i >= (upper_layers_only ? 1 : 0); i--) {
         LayerStore& Ls = layers_[i];
         uint32_t ns;
         if (MT) ns = new_slots[i];
@@ -403,12 +406,15 @@ void HostIndex::insert_one(uint32_t id, const float* q, int level, const uint32_
         // (concurrent build: another insert may have reached this vector through its node in the layer above and linked to
         // it already, so the search could arrive at the vector itself — it is not its own neighbour)
         if (MT) s.test_and_set(id);
-        if (i == 0 && cand_cnt > 0) {
-            // layer 0's candidate list comes from outside (a search from the top of the graph as it stood; the reference
+        if (i == cand_layer && cand_cnt > 0 && (i == 0 || slot1_of)) {
+            // this layer's candidate list comes from outside (a search from the top of the graph as it stood; the reference
             // seeds this search with the whole result of the layer above instead, src/hnsw.cpp:246-262)
             s.W.clear();
             for (uint32_t c = 0; c < cand_cnt; c++)
-                if (cand_ids[c] != id) s.W.push_back(Neighbor{cand_dist[c], cand_ids[c], cand_ids[c]});      // (layer 0: slot = node_order)
+                if (cand_ids[c] != id) {
+                    const uint32_t sl = i == 0 ? cand_ids[c] : slot1_of[cand_ids[c]];                 // (layer 0: slot = node_order)
+                    if (sl != kPad) s.W.push_back(Neighbor{cand_dist[c], cand_ids[c], sl});
+                }
         } else {
             search_layer<MT>(i, q, efConstruction_, s);
         }
@@ -460,7 +466,7 @@ void HostIndex::ensure_locks()
     }
 }
 
-void HostIndex::insert_batch(const float* rows, uint32_t n, int threads, CandidateSearchFn candidates, void* ctx)
+void HostIndex::insert_batch(const float* rows, uint32_t n, int threads, CandidateSearchFn candidates, void* ctx, const Layer0Linker* layer0)
 {
     if (max_node_count_ <= 0) throw std::invalid_argument("insert_batch: init() has not been called");
     if (build_failed_) throw std::logic_error("insert_batch: an earlier concurrent build failed half way; init() the index again");
@@ -478,8 +484,8 @@ void HostIndex::insert_batch(const float* rows, uint32_t n, int threads, Candida
     for (uint32_t i = 0; i < n; i++) level[i] = draw_level();
     std::memcpy(&vector_data_[(size_t)first * vector_size_], rows, sizeof(float) * (size_t)n * vector_size_);
 
-    // a sequential prefix builds the upper structure
-    uint32_t warm = std::min<uint32_t>(n, 1024);
+    // a sequential prefix builds the upper structure of an index that is still small
+    uint32_t warm = first >= 1024u ? 0u : std::min<uint32_t>(n, 1024u - first);
     for (uint32_t i = 0; i < warm; i++) {
         uint32_t id = (uint32_t)++actual_node_count_;
         insert_one<false>(id, row(id), level[i], nullptr, *scratch_);
@@ -511,6 +517,9 @@ void HostIndex::insert_batch(const float* rows, uint32_t n, int threads, Candida
     // searches can: device memory, a HIP error) the segment's nodes are in the layers but not all linked: the index
     // is marked as failed, and the version moves so that no device copy passes for current.
     uint32_t seg_begin = warm;
+    std::vector<std::unique_ptr<Scratch>> scratch_pool;      // one per worker thread, for the whole call
+    std::vector<uint32_t> slot1_of;                   // (device-linked build) node_order -> slot in layer 1
+    std::vector<uint32_t> upper_rank(layer0 ? n : 0u, 0u);   // ... rank of a vector among those of its sub-batch that live in layer 1
     try {
     while (seg_begin < n) {
         uint32_t seg_end = seg_begin;
@@ -526,16 +535,25 @@ void HostIndex::insert_batch(const float* rows, uint32_t n, int threads, Candida
             }
             ensure_locks();
             actual_node_count_ = (int)(first + seg_end - 1);
+            if (layer0 && layers_.size() > 1) {
+                // layer-1 slot of every vector that has one (candidate lists name vectors, lists hold slots)
+                const LayerStore& L1 = layers_[1];
+                slot1_of.assign((size_t)max_node_count_, kPad);
+                for (uint32_t sl = 0; sl < L1.count; sl++) slot1_of[L1.order[sl]] = sl;
+            }
             // vectors [lo, hi) of the batch, by a pool of threads; `cand` (optional): for vector lo + j the result list
             // of a layer-0 search with ef = efConstruction_ run elsewhere, cand_cnt[j] entries at cand_ids/cand_dist + j * ef
-            auto run_range = [&](uint32_t lo, uint32_t hi, const uint32_t* cand_ids, const float* cand_dist, const uint32_t* cand_cnt) {
+            auto run_range = [&](uint32_t lo, uint32_t hi, const uint32_t* cand_ids, const float* cand_dist, const uint32_t* cand_cnt,
+                                 bool upper_only = false) {
                 std::atomic<uint32_t> cursor{lo};
                 std::vector<std::thread> pool;
                 std::exception_ptr err; std::mutex err_mu;
                 int nt = std::min<int>(threads, 256);
+                // (a thread's working state outlives the sub-batch: its visited stamps are as long as the index)
+                while ((int)scratch_pool.size() < nt) scratch_pool.emplace_back(new Scratch());
                 for (int t = 0; t < nt; t++) {
-                    pool.emplace_back([&]() {
-                        Scratch s;
+                    pool.emplace_back([&, t]() {
+                        Scratch& s = *scratch_pool[t];
                         try {
                             for (;;) {
                                 uint32_t i = cursor.fetch_add(1);
@@ -543,7 +561,18 @@ void HostIndex::insert_batch(const float* rows, uint32_t n, int threads, Candida
                                 uint32_t id = first + i;
                                 const uint32_t j = i - lo;
                                 const size_t at = (size_t)j * (size_t)efConstruction_;
-                                if (cand_ids && slots[i].size() == 1 && cand_cnt[j] > 0) {
+                                if (upper_only) {
+                                    // layer 0 is linked elsewhere: the layers above for the one vector in sixteen that has any, with
+                                    // layer 1's candidate list from there as well (cand_cnt is indexed by the vector's rank among them)
+                                    if (slots[i].size() > 1) {
+                                        const uint32_t u = upper_rank[i];
+                                        const size_t ua = (size_t)u * (size_t)efConstruction_;
+                                        if (cand_ids && cand_cnt[u] > 0)
+                                            insert_one<true>(id, row(id), level[i], slots[i].data(), s, cand_ids + ua, cand_dist + ua, cand_cnt[u], true, slot1_of.data());
+                                        else
+                                            insert_one<true>(id, row(id), level[i], slots[i].data(), s, nullptr, nullptr, 0, true);
+                                    }
+                                } else if (cand_ids && slots[i].size() == 1 && cand_cnt[j] > 0) {
                                     // a vector that lives in layer 0 only: the reference's insert would run exactly that
                                     // search (src/hnsw.cpp:241-262); select and link as usual
                                     s.W.clear();
@@ -565,17 +594,70 @@ void HostIndex::insert_batch(const float* rows, uint32_t n, int threads, Candida
                 for (auto& th : pool) th.join();
                 if (err) std::rethrow_exception(err);
             };
-            if (!candidates) {
+            // (a sixteenth of what is linked, 16384 at most; while the graph is small a quarter of it, up to 1024)
+            auto sub_batch = [&](uint32_t pos) {
+                const uint32_t linked = first + pos;
+                return std::min<uint32_t>(16384u, std::max<uint32_t>(std::min<uint32_t>(1024u, std::max<uint32_t>(64u, linked / 4u)), linked / 16u));
+            };
+            if (layer0) {
+                // Layer 0 on the device from here to the end of the segment.  A sub-batch is searched, selected and linked
+                // there on the graph as it stands (its vectors do not see each other); only after that are its vectors linked
+                // into the layers above on the host — while the device works on the next sub-batch, which descends through
+                // the upper layers as they were handed over before that linking began.  So no search ever descends into a
+                // vector whose layer-0 list does not exist yet.
+                layer0->from_host(layer0->ctx);
+                uint32_t prev_pos = 0, prev_end = 0;                      // the sub-batch whose upper layers are still to be linked
+                // candidate lists of the layer-1 searches: of the sub-batch in the device's hands, and of the one before it
+                std::vector<uint32_t> uids, cids[2], ccnt[2]; std::vector<float> cdist[2];
+                int cur = 0;
+                for (uint32_t pos = seg_begin; pos < seg_end;) {
+                    const uint32_t end = std::min<uint32_t>(seg_end, pos + sub_batch(pos));
+                    const auto t0 = std::chrono::steady_clock::now();
+                    uids.clear();
+                    for (uint32_t i = pos; i < end; i++)
+                        if (slots[i].size() > 1) { upper_rank[i] = (uint32_t)uids.size(); uids.push_back(first + i); }
+                    cids[cur].resize(uids.size() * (size_t)efConstruction_); cdist[cur].resize(uids.size() * (size_t)efConstruction_);
+                    ccnt[cur].assign(uids.size(), 0u);
+                    layer0->upper_layers(layer0->ctx);
+                    std::exception_ptr dev_err;
+                    double dev_s = 0.0;
+                    std::thread dev_thread([&]() {
+                        try {
+                            layer0->step(layer0->ctx, first + pos, end - pos, uids.data(), (uint32_t)uids.size(), cids[cur].data(), cdist[cur].data(),
+                                         ccnt[cur].data());
+                        } catch (...) { dev_err = std::current_exception(); }
+                        dev_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                    });
+                    const auto t1 = std::chrono::steady_clock::now();
+                    std::exception_ptr host_err;
+                    try {
+                        if (prev_end > prev_pos) run_range(prev_pos, prev_end, cids[cur ^ 1].data(), cdist[cur ^ 1].data(), ccnt[cur ^ 1].data(), true);
+                    } catch (...) { host_err = std::current_exception(); }
+                    const auto t2 = std::chrono::steady_clock::now();
+                    dev_thread.join();
+                    if (dev_err) std::rethrow_exception(dev_err);
+                    if (host_err) std::rethrow_exception(host_err);
+                    assisted_search_s += dev_s;
+                    assisted_link_s += std::chrono::duration<double>(t2 - t1).count();
+                    assisted_batches++;
+                    prev_pos = pos; prev_end = end;
+                    cur ^= 1;
+                    pos = end;
+                }
+                if (prev_end > prev_pos) {
+                    const auto t1 = std::chrono::steady_clock::now();
+                    run_range(prev_pos, prev_end, cids[cur ^ 1].data(), cdist[cur ^ 1].data(), ccnt[cur ^ 1].data(), true);
+                    assisted_link_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+                }
+                layer0->to_host(layer0->ctx);
+            } else if (!candidates) {
                 run_range(seg_begin, seg_end, nullptr, nullptr, nullptr);
             } else {
                 // Candidate lists from outside (the GPU): the graph is frozen while a sub-batch is searched, so the vectors
                 // of a sub-batch do not see each other; sub-batches stay small next to what is linked already.
                 std::vector<uint32_t> cids, ccnt; std::vector<float> cdist;
                 for (uint32_t pos = seg_begin; pos < seg_end;) {
-                    const uint32_t linked = first + pos;
-                    // (a sixteenth of what is linked, 16384 at most; while the graph is small a quarter of it, up to 1024)
-                    const uint32_t want = std::min<uint32_t>(16384u, std::max<uint32_t>(std::min<uint32_t>(1024u, std::max<uint32_t>(64u, linked / 4u)), linked / 16u));
-                    const uint32_t end = std::min<uint32_t>(seg_end, pos + want);
+                    const uint32_t end = std::min<uint32_t>(seg_end, pos + sub_batch(pos));
                     const uint32_t cnt = end - pos;
                     cids.resize((size_t)cnt * efConstruction_); cdist.resize((size_t)cnt * efConstruction_); ccnt.assign(cnt, 0);
                     const auto t0 = std::chrono::steady_clock::now();
@@ -607,9 +689,10 @@ void HostIndex::insert_batch(const float* rows, uint32_t n, int threads, Candida
     }
     actual_node_count_ = (int)(first + n - 1);
     version_++;
-    if (candidates && getenv("HNSW_AMD_VERBOSE"))
-        fprintf(stderr, "[hnsw_amd] assisted build: %u sub-batches so far, %.2f s in candidate searches (graph refresh included), %.2f s selecting and linking\n",
-                assisted_batches, assisted_search_s, assisted_link_s);
+    if ((candidates || layer0) && getenv("HNSW_AMD_VERBOSE"))
+        fprintf(stderr, "[hnsw_amd] assisted build: %u sub-batches so far, %.2f s in %s, %.2f s selecting and linking on the host%s\n",
+                assisted_batches, assisted_search_s, layer0 ? "the device steps (search, selection, linking of layer 0)" : "candidate searches (graph refresh included)",
+                assisted_link_s, layer0 ? " (upper layers, at the same time as the device steps)" : "");
 }
 
 // ---------------------------------------------------------------------------------------

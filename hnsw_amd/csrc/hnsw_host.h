@@ -69,7 +69,8 @@ public:
                                        // init / load_graph / import_flat replaces it, so a device copy of the rows knows whose rows it holds
     bool build_failed_ = false;        // a concurrent build stopped half way (nodes added, not all linked): searches and inserts refuse until
                                        // init / load_graph / import_flat starts over
-    double assisted_search_s = 0.0, assisted_link_s = 0.0;   // where an assisted build's time went (HNSW_AMD_VERBOSE prints them)
+    double assisted_search_s = 0.0, assisted_link_s = 0.0;   // where an assisted build's time went (HNSW_AMD_VERBOSE prints them):
+                                                             // candidate searches (device-linked build: the whole device step), host selecting and linking
     uint32_t assisted_batches = 0;
 
     HostIndex(int M, int Mmax, int efConstruction);
@@ -82,7 +83,25 @@ public:
     typedef void (*CandidateSearchFn)(void* ctx, const float* queries, uint32_t nq, int ef, uint32_t* ids, float* dist, uint32_t* cnt);
     // threads > 1: concurrent.  With `candidates`, vectors that live in layer 0 only take their candidate lists from it
     // (in sub-batches, between which it sees the graph again) instead of searching on the host.
-    void insert_batch(const float* rows, uint32_t n, int threads, CandidateSearchFn candidates = nullptr, void* ctx = nullptr);
+    // With `layer0`, layer 0 of the concurrent build lives somewhere else (the GPU) between from_host and to_host: each
+    // sub-batch is searched, selected and linked there by step(), and the host threads only insert the sub-batch's
+    // vectors into the layers above.  from_host: the graph as the host has it now is the starting point; upper_layers:
+    // the layers above as the host has them now are what the next step descends through (called while no host thread
+    // changes them); step: called from a thread of its own while the host threads link the previous sub-batch into the
+    // upper layers — it may read vector_data_ and nothing else of the index; to_host: layer 0's lists, edge distances
+    // and counts are written back into layers_[0].
+    struct Layer0Linker {
+        void* ctx;
+        void (*from_host)(void* ctx);
+        void (*upper_layers)(void* ctx);
+        // upper_ids: those of the step's vectors that also live in layer 1; their layer-1 candidate lists come back in
+        // cand_ids / cand_dist (efConstruction entries each) and cand_cnt (0: none, the host searches itself)
+        void (*step)(void* ctx, uint32_t first_id, uint32_t cnt, const uint32_t* upper_ids, uint32_t n_upper,
+                     uint32_t* cand_ids, float* cand_dist, uint32_t* cand_cnt);
+        void (*to_host)(void* ctx);
+    };
+    void insert_batch(const float* rows, uint32_t n, int threads, CandidateSearchFn candidates = nullptr, void* ctx = nullptr,
+                      const Layer0Linker* layer0 = nullptr);
     void save_graph(const char* filename) const;                   // reference file format
     void load_graph(const char* filename);
     void import_flat(const FlatGraph& g, const float* vectors);
@@ -101,7 +120,8 @@ private:
     void validate_loaded(const char* filename) const;
     int draw_level();
     template <bool MT> void insert_one(uint32_t id, const float* q, int level, const uint32_t* new_slots, Scratch& s,
-                                       const uint32_t* cand_ids = nullptr, const float* cand_dist = nullptr, uint32_t cand_cnt = 0);
+                                       const uint32_t* cand_ids = nullptr, const float* cand_dist = nullptr, uint32_t cand_cnt = 0,
+                                       bool upper_layers_only = false, const uint32_t* slot1_of = nullptr);
     template <bool MT> void search_layer_one(int layer, const float* q, Scratch& s);
     template <bool MT> void search_layer(int layer, const float* q, int ef, Scratch& s);
     void select_neighbors(std::vector<Neighbor>& W, std::vector<Neighbor>& R, int M, int layer) const;

@@ -1872,7 +1872,7 @@ void DeviceIndex::upload(const HostIndex& h, int dev)
 // The graph of an index whose vectors are on the device already (same rows, same list lengths): the neighbour lists
 // and the upper layers are copied again, nothing else.  The host keeps layer 0's lists in the device's own layout
 // (node_order per slot, 0xFFFFFFFF padding), so that part is one copy.
-void DeviceIndex::refresh_graph(const HostIndex& h)
+void DeviceIndex::refresh_graph(const HostIndex& h, bool with_layer0, FlatGraph* exported)
 {
     if (device < 0 || !g.vectors) throw std::logic_error("refresh_graph: index not on a device");
     if (calls_in_flight()) throw std::logic_error("the index was changed while a search call on it was in flight: finish the call first");
@@ -1881,9 +1881,11 @@ void DeviceIndex::refresh_graph(const HostIndex& h)
     h.export_flat(fg, false);
     if (fg.n != g.n || fg.d != g.d || fg.deg0 != g.deg0 || fg.degu != g.degu || fg.nlayers == 0)
         throw std::logic_error("refresh_graph: the index changed shape");
-    const std::vector<uint32_t>& lists0 = h.layers_[0].nb_order;
-    if (lists0.size() < (size_t)g.n * g.deg0) throw std::logic_error("refresh_graph: layer 0 is shorter than the index");
-    HIP_CHECK(hipMemcpy(const_cast<uint32_t*>(g.adj0), lists0.data(), (size_t)g.n * g.deg0 * 4, hipMemcpyHostToDevice));
+    if (with_layer0) {
+        const std::vector<uint32_t>& lists0 = h.layers_[0].nb_order;
+        if (lists0.size() < (size_t)g.n * g.deg0) throw std::logic_error("refresh_graph: layer 0 is shorter than the index");
+        HIP_CHECK(hipMemcpy(const_cast<uint32_t*>(g.adj0), lists0.data(), (size_t)g.n * g.deg0 * 4, hipMemcpyHostToDevice));
+    }
     for (int b = 2; b <= 5; b++) { if (bufs_[b]) HIP_CHECK(hipFree(bufs_[b])); bufs_[b] = nullptr; }
     g.nlayers = fg.nlayers;
     g.top_ep_slot = fg.ep_slot[fg.nlayers - 1]; g.top_ep_order = fg.ep_order[fg.nlayers - 1];
@@ -1892,7 +1894,25 @@ void DeviceIndex::refresh_graph(const HostIndex& h)
     g.up_adj_slot = to_device(fg.up_adj_slot, bufs_[4]);
     g.up_adj_order = to_device(fg.up_adj_order, bufs_[5]);
     HIP_CHECK(hipDeviceSynchronize());
-    version = h.version_;
+    if (with_layer0) version = h.version_;
+    if (exported) *exported = std::move(fg);
+}
+
+uint32_t DeviceIndex::search_on(const DeviceGraph& view, const float* d_queries, uint32_t nq, int ef, uint32_t out_k, uint32_t flags,
+                                uint32_t* d_ids, float* d_dist, uint32_t* d_count, void* stream)
+{
+    if (calls_in_flight()) throw std::logic_error("search_on: a search call on the index is in flight");
+    const DeviceGraph own = g;
+    g = view;
+    uint32_t r = 0;
+    try {
+        r = search(d_queries, nq, ef, out_k, flags | kFlagView, d_ids, d_dist, d_count, nullptr, stream);
+    } catch (...) {
+        g = own;
+        throw;
+    }
+    g = own;
+    return r;
 }
 
 void DeviceIndex::ensure_quantized(const HostIndex& h)

@@ -64,13 +64,16 @@ class HNSW:
         capi.check(capi.lib().hnsw_amd_load_graph(self._h, filename.encode()))
 
     # -- batched / device entry points ---------------------------------------------------
-    def insert_batch(self, rows: np.ndarray, threads: int = 1, gpu: bool = False) -> None:
+    def insert_batch(self, rows: np.ndarray, threads: int = 1, gpu=False) -> None:
         """threads > 1: concurrent build.  gpu=True: the construction searches of layer-0-only vectors run on the GPU
-        (hnsw_amd_insert_batch_assisted)."""
+        (hnsw_amd_insert_batch_assisted); gpu="link": selection and linking of layer 0 run there as well
+        (hnsw_amd_insert_batch_linked)."""
         rows = np.ascontiguousarray(rows, dtype=np.float32)
         if rows.ndim != 2 or rows.shape[1] != self.vector_size_:
             raise ValueError("insert_batch: rows must be n x vector_size")
-        if gpu:
+        if gpu == "link":
+            capi.check(capi.lib().hnsw_amd_insert_batch_linked(self._h, capi.f32(rows), rows.shape[0], threads, self.device))
+        elif gpu:
             capi.check(capi.lib().hnsw_amd_insert_batch_assisted(self._h, capi.f32(rows), rows.shape[0], threads, self.device))
         else:
             capi.check(capi.lib().hnsw_amd_insert_batch(self._h, capi.f32(rows), rows.shape[0], threads))

@@ -130,6 +130,18 @@ int hnsw_amd_insert_batch(hnsw_amd_index* h, const float* rows, uint32_t n, int 
  * candidate search) the index is left unusable: every later insert or search returns HNSW_AMD_E_ARG until
  * hnsw_amd_init / hnsw_amd_load_graph / hnsw_amd_import_flat starts it over. */
 int hnsw_amd_insert_batch_assisted(hnsw_amd_index* h, const float* rows, uint32_t n, int threads, int device);
+/* The same loop with all of layer 0 on the GPU: after the search of a sub-batch (as above), selectNeighbors for the new
+ * vectors (src/hnsw.cpp:263, 1078-1126), their own lists, the links back from every selected neighbour and the
+ * re-selection of a neighbour's list that is full (src/hnsw.cpp:266-312) run as kernels on the device's copy of layer 0;
+ * the links of a sub-batch are sorted by neighbour and every neighbour's list is updated by one wavefront, in the order
+ * of the new vectors' ids, so the graph does not depend on timing.  The host threads only insert the one vector in
+ * sixteen that lives in upper layers into those layers; layer 0 is copied back into the host's arrays when the call
+ * ends (and around a vector that opens a new top layer, which is inserted on the host).  Distances between two stored
+ * vectors are summed in another order than insert() does, so comparisons that are near-ties may fall differently: a
+ * valid HNSW graph of the same rule, neither the reference's exact adjacency nor the assisted build's.  For M <= Mmax0
+ * <= 32 and efConstruction <= 4096; anything else is built by hnsw_amd_insert_batch_assisted.  Same conditions, same
+ * behaviour after a failure. */
+int hnsw_amd_insert_batch_linked(hnsw_amd_index* h, const float* rows, uint32_t n, int threads, int device);
 /* Construction option with no counterpart in the reference: key the candidate heap of the searches that insert()
  * runs by the float distance instead of the reference's int32 truncation (src/hnsw.cpp:727,767).  Off by default
  * (the sequential build then reproduces the reference's graph).  On unit-norm data the truncated keys are all 0..3,

@@ -216,6 +216,14 @@ public:
         refresh();
         if (mirror_layers) syncLayers();
     }
+    // ... and with selection and linking of layer 0 on the GPU as well (hnsw_amd_insert_batch_linked): the host threads only
+    // insert into the upper layers
+    void insertBatchDevice(const float* rows, uint32_t n, int threads, int device = 0)
+    {
+        check(hnsw_amd_insert_batch_linked(h_, rows, n, threads, device));
+        refresh();
+        if (mirror_layers) syncLayers();
+    }
     // construction searches keyed by the float distance instead of the int32 truncation (see hnsw_amd.h)
     void setBuildFloatKeys(bool on) { check(hnsw_amd_set_build_float_keys(h_, on ? 1 : 0)); }
     // insert() with the distance of a -DNO_MANUAL_VECTORIZATION build of the reference (src/hnsw.h:387-400) instead of the shipped SSE loop

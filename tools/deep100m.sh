@@ -1,6 +1,6 @@
 #!/bin/bash
-# The DEEP-96 100M configuration as one command: 8 ranks (one per GPU) over RCCL, 12.5M rows each, GPU-assisted build
-# with float construction keys, search with the reference's int32 keys, all-gather + device merge.
+# The DEEP-96 100M configuration as one command: 8 ranks (one per GPU) over RCCL, 12.5M rows each, layer 0 built on the GPU
+# (search, selection, linking) with float construction keys, search with the reference's int32 keys, all-gather + device merge.
 #   bash tools/deep100m.sh                 the configuration itself (8-GPU node; about 16 GB of host memory per rank)
 #   bash tools/deep100m.sh rehearse        the same code path with 2 ranks over gloo sharing one GPU, 400k rows
 set -eu
