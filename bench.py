@@ -120,7 +120,7 @@ def main():
     lo = prank * args.n // parts
     hi = (prank + 1) * args.n // parts
     t0 = time.time()
-    base = datagen.make(args.kind, hi - lo, seed=1, stream=0, row0=lo)
+    base = datagen.make(args.kind, hi - lo, seed=1, stream=0, row0=lo, threads=args.build_threads)
     # replicated: every rank has its own batch of queries (rows rank*nq .. of the query stream)
     queries = datagen.make(args.kind, args.nq, seed=1, stream=1, row0=0 if parts == world else rank * args.nq)
     log(f"rank {rank}: data {base.shape} in {time.time() - t0:.1f}s")

@@ -107,9 +107,22 @@ KINDS = {
 }
 
 
-def make(kind: str, n: int, seed: int = 1, stream: int = 0, *, row0: int = 0, d: int | None = None) -> np.ndarray:
-    """Rows [row0, row0+n) of the synthetic set `kind` as float32 (n x d)."""
+def make(kind: str, n: int, seed: int = 1, stream: int = 0, *, row0: int = 0, d: int | None = None, threads: int = 1) -> np.ndarray:
+    """Rows [row0, row0+n) of the synthetic set `kind` as float32 (n x d).  threads > 1: slices of the rows are generated
+    side by side (every row depends on its own index only, so the result is the same)."""
     d = KINDS[kind] if d is None else d
+    if threads > 1 and n >= (1 << 18):
+        from concurrent.futures import ThreadPoolExecutor
+        out = np.empty((n, d), dtype=np.float32)
+        step = -(-n // (4 * threads))
+        step = -(-step // (1 << 16)) * (1 << 16)
+
+        def part(lo: int) -> None:
+            out[lo:lo + step] = make(kind, min(step, n - lo), seed, stream, row0=row0 + lo, d=d)
+
+        with ThreadPoolExecutor(threads) as pool:
+            list(pool.map(part, range(0, n, step)))
+        return out
     x = integer_vectors(n, d, seed=seed * 1000 + sorted(KINDS).index(kind), stream=stream, row0=row0)
     if kind in ("sift", "fmnist"):
         return x

@@ -30,6 +30,7 @@ ap.add_argument("--k", type=int, default=10)
 ap.add_argument("--threads", type=int, default=16)
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--build-keys", default="float", choices=["int32", "float"])
+ap.add_argument("--build", default="device", choices=["gpu", "device"], help="gpu: the host links (assisted build); device: layer 0 linked on the GPU")
 args = ap.parse_args()
 
 S, ns, nq, k = args.shards, args.rows_per_shard, args.nq, args.k
@@ -43,13 +44,13 @@ gt_d = torch.full((nq, k), float("inf"), device=dev)
 gt_i = torch.zeros((nq, k), dtype=torch.int64, device=dev)
 for s in range(S):
     t0 = time.time()
-    rows = datagen.make(args.kind, ns, seed=1, stream=0, row0=s * ns)
+    rows = datagen.make(args.kind, ns, seed=1, stream=0, row0=s * ns, threads=args.threads)
     h = HNSW(16, 16, 200)
     h.init(d, ns)
     if args.build_keys == "float":
         h.set_build_float_keys(True)
     t1 = time.time()
-    h.insert_batch(rows, threads=args.threads, gpu=True)
+    h.insert_batch(rows, threads=args.threads, gpu=("link" if args.build == "device" else True))
     build_s.append(round(time.time() - t1, 1))
     h.sync_device(0)
     # exact ground truth of this slice, folded into the running global top-k
@@ -78,6 +79,27 @@ def one_pass(ef):
                                                      2 * nq * k, out_i.data_ptr(), out_d.data_ptr(), stream))
 
 
+side_streams = [torch.cuda.Stream() for _ in range(2)]
+
+
+def one_pass_overlapped(ef):
+    """The same pass with two shard searches in flight (the call in two halves, a stream each): the next shard's queries
+    take the slots the last queries of the previous one leave idle."""
+    torch.cuda.synchronize()
+    calls = []
+    for s, h in enumerate(shards):
+        if len(calls) == 2:
+            hh, c = calls.pop(0)
+            hh.search_batch_device_finish(c)
+        calls.append((h, h.search_batch_device_begin(q_t.data_ptr(), nq, ef, k, gathered[s, 1].data_ptr(), gathered[s, 0].data_ptr(), 0, 0,
+                                                     side_streams[s % 2].cuda_stream, flags)))
+    for hh, c in calls:
+        hh.search_batch_device_finish(c)
+    torch.cuda.synchronize()
+    capi.check(capi.lib().hnsw_amd_merge_topk_device(gathered.data_ptr(), gathered.data_ptr() + 4 * nq * k, capi.u32(offsets), S, nq, k, k,
+                                                     2 * nq * k, out_i.data_ptr(), out_d.data_ptr(), stream))
+
+
 gt = gt_i.cpu().numpy()
 for ef in [int(x) for x in args.ef.split(",")]:
     for _ in range(3):
@@ -90,9 +112,19 @@ for ef in [int(x) for x in args.ef.split(",")]:
     ms = (time.perf_counter() - t0) / args.steps * 1e3
     got = out_i.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
     recall = harness.recall_at_k(got, gt, k)
+    for _ in range(2):
+        one_pass_overlapped(ef)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_pass_overlapped(ef)
+    torch.cuda.synchronize()
+    ms2 = (time.perf_counter() - t0) / args.steps * 1e3
+    same = bool(np.array_equal(got, out_i.cpu().numpy().astype(np.int64) & 0xFFFFFFFF))
     print(json.dumps({"workload": f"{args.kind}-{d} synthetic, {S} shards x {ns} rows = {S * ns} rows, nq={nq}, ef={ef}, k={k}, keys=int32, "
-                                  f"graphs built the GPU-assisted way ({args.build_keys} build keys), all shards on one GPU",
+                                  f"graphs built {'with layer 0 linked on the GPU' if args.build == 'device' else 'the GPU-assisted way'} ({args.build_keys} build keys), all shards on one GPU",
                       "ef": ef, "build_s_per_shard": build_s, "recall_at_10_merged": round(float(recall), 4),
                       "ms_per_pass_one_gpu_all_shards": round(ms, 3), "queries_per_s_one_gpu_all_shards": round(nq / ms * 1e3, 1),
+                      "two_shard_searches_in_flight": {"ms_per_pass": round(ms2, 3), "queries_per_s": round(nq / ms2 * 1e3, 1), "same_result": same},
                       "note": "one pass = S shard searches + device merge on one GPU; S GPUs run the searches side by side and add an "
                               "all-gather of 80 KB x S per 1000 queries"}), flush=True)
