@@ -169,3 +169,26 @@ def test_concurrent_build_keeps_the_list_invariants(kind, n):
         up = g.up_adj_order.reshape(U, g.degu)
         ulive = np.arange(g.degu)[None, :] < g.up_cnt[:, None]
         assert not (up == g.up_order[:, None])[ulive].any()
+
+
+def test_rows_generated_in_slices_side_by_side_are_the_same_rows():
+    """datagen.make(threads > 1) generates slices of the rows concurrently; every row depends on its own index only."""
+    for kind in ("sift", "deep"):
+        a = datagen.make(kind, 300_000, seed=3, row0=12_345)
+        b = datagen.make(kind, 300_000, seed=3, row0=12_345, threads=4)
+        assert np.array_equal(a, b)
+
+
+def test_concurrent_build_grows_an_index_over_several_calls():
+    """Only a small index gets a sequential prefix; later calls go straight to the concurrent path."""
+    base = datagen.make("sift", 9000, seed=5)
+    h = HNSW(16, 16, 100)
+    h.init(128, 9000)
+    h.insert_batch(base[:3000], threads=4)
+    h.insert_batch(base[3000:6000], threads=4)
+    h.insert_batch(base[6000:], threads=4)
+    g = h.export_flat()
+    assert g.n == 9000 and g.cnt0.min() >= 1
+    adj = g.adj0.reshape(9000, g.deg0)
+    live = np.arange(g.deg0)[None, :] < g.cnt0[:, None]
+    assert (adj[live] < 9000).all() and not (adj == np.arange(9000, dtype=np.uint32)[:, None]).any()
