@@ -594,10 +594,12 @@ void HostIndex::insert_batch(const float* rows, uint32_t n, int threads, Candida
                 for (auto& th : pool) th.join();
                 if (err) std::rethrow_exception(err);
             };
-            // (a sixteenth of what is linked, 16384 at most; while the graph is small a quarter of it, up to 1024)
+            // (a sixteenth of what is linked, 16384 at most — beyond a million linked vectors a sixty-fourth, 65536 at most, so
+            // that the per-sub-batch hand-overs stay a small part of a large build; while the graph is small a quarter of it, up to 1024)
             auto sub_batch = [&](uint32_t pos) {
                 const uint32_t linked = first + pos;
-                return std::min<uint32_t>(16384u, std::max<uint32_t>(std::min<uint32_t>(1024u, std::max<uint32_t>(64u, linked / 4u)), linked / 16u));
+                const uint32_t cap = std::min<uint32_t>(65536u, std::max<uint32_t>(16384u, linked / 64u));
+                return std::min<uint32_t>(cap, std::max<uint32_t>(std::min<uint32_t>(1024u, std::max<uint32_t>(64u, linked / 4u)), linked / 16u));
             };
             if (layer0) {
                 // Layer 0 on the device from here to the end of the segment.  A sub-batch is searched, selected and linked

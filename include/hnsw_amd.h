@@ -123,7 +123,7 @@ int hnsw_amd_insert_batch(hnsw_amd_index* h, const float* rows, uint32_t n, int 
 /* The same loop with the construction searches of layer-0-only vectors (19 in 20) run on the GPU: HNSW::insert's
  * searchLayer(q, efConstruction) (src/hnsw.cpp:246-262) is the query path, so the batched search kernel supplies the
  * candidate lists of a sub-batch at a time on the graph as it stands (a sub-batch is a sixteenth of the nodes linked
- * so far, 16384 rows at most; while the graph is small, a quarter of it up to 1024 rows), and the host threads run selectNeighbors and the linking (src/hnsw.cpp:263-323,
+ * so far, 16384 rows at most — beyond a million linked nodes a sixty-fourth, 65536 at most; while the graph is small, a quarter of it up to 1024 rows), and the host threads run selectNeighbors and the linking (src/hnsw.cpp:263-323,
  * 1078-1126) as in the concurrent build.  Vectors of one sub-batch do not see each other: a valid HNSW graph of the
  * same rule, not the reference's exact adjacency.  Needs threads > 1 and n >= 2048 (else: hnsw_amd_insert_batch).
  * `device`: the GPU that searches (and holds the index afterwards).  If the build fails half way (a HIP error in a
