@@ -354,7 +354,7 @@ public:
             for (size_t j = 0; j < d; j++) rows[i * d + j] *= inv;
         }
     }
-    // (gpu_build: the construction searches run on GPU `device`, see insertBatchGpu)
+    // (gpu_build: layer 0 is searched, selected and linked on GPU `device`, see insertBatchDevice)
     void create(const char* filename, const char* datasetname, int threads = 1, bool normalize = false, bool gpu_build = false, int device = 0)
     {
         hsize_t dims[2] = {0, 0};
@@ -365,7 +365,7 @@ public:
         std::vector<float> data((size_t)dims[0] * dims[1]);
         hdfReader::readData(filename, datasetname, data.data());
         if (normalize) normalizeRows(data.data(), (size_t)dims[0], (size_t)dims[1]);
-        if (gpu_build) insertBatchGpu(data.data(), (uint32_t)dims[0], threads, device);
+        if (gpu_build) insertBatchDevice(data.data(), (uint32_t)dims[0], threads, device);
         else insertBatch(data.data(), (uint32_t)dims[0], threads);       // (keeps layers_ current when mirror_layers is set)
     }
     double query(const char* filename, const char* querydatasetname, const char* resultdatasetname, int ef, bool normalize = false)

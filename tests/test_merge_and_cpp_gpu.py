@@ -103,6 +103,26 @@ def test_cpp_hdf5_create_and_query(tmp_path):
         assert abs(reference_precision(ids, gt, 10) - p) < 1e-6
 
 
+def test_cpp_hdf5_create_with_the_index_built_on_the_gpu(tmp_path):
+    """create(..., gpu_build = true): layer 0 searched, selected and linked on the GPU; the driver's precision is that
+    of a sound graph."""
+    from tests import hdf5_writer
+    if not hdf5_writer.available():
+        pytest.skip("libhdf5 not found")
+    exe = os.path.join(ROOT, "examples", "hdf5_test")
+    n, nq = 20_000, 150
+    base = datagen.make("sift", n, seed=6)
+    q = datagen.make("sift", nq, seed=6, stream=1)
+    from oracle import oracle
+    gt = oracle.bruteforce(base, q, 100, threads=8).astype(np.int32)
+    path = str(tmp_path / "set.hdf5")
+    hdf5_writer.write(path, {"train": base, "test": q, "neighbors": gt})
+    out = subprocess.run([exe, path, "8", "l2+gpu", "100"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    got = [float(l.split()[1].rstrip(",")) for l in out.stdout.splitlines() if l.startswith("Precision:")]
+    assert len(got) == 1 and got[0] > 0.99
+
+
 def test_cpp_hdf5_angular_set_is_normalised_on_load(tmp_path):
     """An angular file (rows of arbitrary length, "neighbors" by cosine): with `angular` the driver scales rows and
     queries to unit length, on which squared L2 ranks like the angle; without it the raw-L2 search misses them."""
