@@ -331,6 +331,8 @@ void DeviceBuild::step(DeviceIndex& dev, const HostIndex& h, uint32_t first_id, 
     if ((uint64_t)first_id + cnt > dev.g.n) throw std::logic_error("device build: vectors beyond the device's copy of the index");
     HIP_CHECK(hipSetDevice(dev.device));
     const uint32_t ef = (uint32_t)h.efConstruction_, M = (uint32_t)h.M_, d = dev.g.d;
+    if (!supports(h) || dev.g.deg0 > (uint32_t)kMaxList || M > dev.g.deg0)
+        throw std::logic_error("device build: list lengths the kernels are not built for");
     grow(d_q, q_words, (size_t)cnt * d);
     grow(d_cids, cand_words, (size_t)cnt * ef);
     grow(d_cdist, cdist_words, (size_t)cnt * ef);
