@@ -51,8 +51,9 @@ while time.time() < t_end:
     if not unit and dist == "sse" and r.random() < 0.4:
         rows = "u8"
     out_k = ef if r.random() < 0.5 else int(r.integers(1, ef + 1))
+    ip = unit and dist == "sse" and rows == "f32" and r.random() < 0.2      # this library's inner-product metric, on unit vectors
     desc = dict(seed=case_seed, unit=unit, d=d, n=n, M=M, efc=efc, dist=dist, build=build, nq=nq, ef=ef, keys_float=keys_float,
-                std_heap=std_heap, rows=rows, out_k=out_k)
+                std_heap=std_heap, rows=rows, out_k=out_k, ip=ip)
     base = datagen.make("deep" if unit else "sift", n, seed=case_seed % 1000 + 1, d=d)
     q = datagen.make("deep" if unit else "sift", nq, seed=case_seed % 1000 + 1, stream=1, d=d)
     if r.random() < 0.15:
@@ -70,13 +71,14 @@ while time.time() < t_end:
         flags = (capi.DIST_SCALAR if dist == "scalar" else capi.DIST_SSE) | (capi.KEYS_FLOAT if keys_float else capi.KEYS_INT32)
         flags |= capi.ROWS_U8 if rows == "u8" else 0
         flags |= capi.W_STD_HEAP if std_heap else 0
+        flags |= capi.METRIC_IP if ip else 0
         ids, ds, cnt, st = h.search_batch(q, ef, out_k=out_k, flags=flags, stats=True)
         if r.random() < 0.5:
             # once more: the second batch is sized from what the first one needed (other forms of the visited set)
             ids2, ds2, cnt2 = h.search_batch(q, ef, out_k=out_k, flags=flags)
             assert np.array_equal(ids, ids2) and np.array_equal(ds.view(np.uint32), ds2.view(np.uint32)) and np.array_equal(cnt, cnt2), "second call differs"
         idx = oracle.OracleIndex(h.export_flat(), base)
-        oi, od, oc, ost = idx.search(q, ef, out_k=out_k, dist_mode=oracle.DIST_SCALAR if dist == "scalar" else oracle.DIST_SSE,
+        oi, od, oc, ost = idx.search(q, ef, out_k=out_k, dist_mode=oracle.DIST_IP if ip else (oracle.DIST_SCALAR if dist == "scalar" else oracle.DIST_SSE),
                                      key_mode=oracle.KEYS_FLOAT if keys_float else oracle.KEYS_INT32, threads=8, stats=True)
         assert np.array_equal(cnt, oc), "counts differ"
         assert_same_results(ids, ds, oi, od, what="fuzz", last_group_open=not (std_heap and out_k == ef))
