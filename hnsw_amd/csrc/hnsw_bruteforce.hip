@@ -80,7 +80,10 @@ struct EmitArgs {
 // fetched from memory about once and then served by the L2s), and asks for its next tile's first operands before it
 // turns to the distances of the current one.
 // TAIL: the rows end inside a k step (d % 32 != 0): the groups of 8 k past the end of a row are skipped.
-template <bool EMIT, bool VEC, bool TAIL>
+// FOLD: d % 32 == 4 (d = 100): instead of a step of its own for four dims, the last full step carries them along — they
+//       sit in the four floats of padding every LDS row has, and cost two matrix instructions per tile pair instead of
+//       a staging step with its two barriers.
+template <bool EMIT, bool VEC, bool TAIL, bool FOLD = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void dist_tile_kernel(const float* __restrict__ Q, const float* __restrict__ X,
                                                         const float* __restrict__ qn, const float* __restrict__ xn,
                                                         uint32_t nq, uint32_t n, uint32_t d, uint32_t x0, uint32_t cw, uint32_t ntx,
@@ -108,6 +111,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
     // Rows outside the tile read the tile's first row instead: what is computed from them is never looked at (the
     // epilogue skips columns and rows outside), and only k beyond the end of a row has to contribute zero — to one operand.
     const int sc = tid & 7, sr0 = tid >> 3;
+    const uint32_t dm = FOLD ? d - 4u : d;                 // the dims the k steps cover
     const float* qt = Q + (size_t)q0 * d;
     const float* xt = nullptr;
     uint32_t xj0 = 0;                         // first column of the tile the staging role points at
@@ -126,8 +130,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
     // Nothing touches the fetched registers before the store to LDS one step later (the zero for k beyond the end of a row
     // is selected there): a use any earlier would put the wait for the loads in front of the matrix instructions.
     float ra[16], rb[16];
+    float4 rx = make_float4(0.f, 0.f, 0.f, 0.f);      // FOLD: the last four dims of row tid of the A tile (tid < 128) or row tid - 128 of the B tile
     bool inside = true;                 // of the values in flight: is their k inside the row
     auto fetch = [&](uint32_t k0) {
+        if constexpr (FOLD) {
+            if (k0 + (uint32_t)kBK >= dm) {             // the last step: its four extra dims
+                const uint32_t r = (uint32_t)tid & 127u;
+                if (tid < 128) rx = *reinterpret_cast<const float4*>(qt + (q0 + r < nq ? r : 0u) * d + dm);
+                else rx = *reinterpret_cast<const float4*>(xt + ((xj0 + r < cw && x0 + xj0 + r < n) ? r : 0u) * d + dm);
+            }
+        }
         const uint32_t kb = k0 + 4u * (uint32_t)sc;
         if constexpr (VEC) {
             // always load (groups past the end of a row read its last group)
@@ -174,15 +186,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[a][b][r] = 0.0f;
 
-        for (uint32_t k0 = 0; k0 < d; k0 += kBK) {
+        for (uint32_t k0 = 0; k0 < dm; k0 += kBK) {
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 *reinterpret_cast<float4*>(&As[(sr0 + 32 * i) * kLd + 4 * sc]) =
                     make_float4(inside ? ra[4 * i] : 0.f, inside ? ra[4 * i + 1] : 0.f, inside ? ra[4 * i + 2] : 0.f, inside ? ra[4 * i + 3] : 0.f);
                 *reinterpret_cast<float4*>(&Bs[(sr0 + 32 * i) * kLd + 4 * sc]) = make_float4(rb[4 * i], rb[4 * i + 1], rb[4 * i + 2], rb[4 * i + 3]);
             }
+            const bool last_step = FOLD && k0 + (uint32_t)kBK >= dm;
+            if (last_step) *reinterpret_cast<float4*>(&(tid < 128 ? As : Bs)[(tid & 127) * kLd + kBK]) = rx;
             __syncthreads();
-            if (k0 + kBK < d) fetch(k0 + kBK);
+            if (k0 + kBK < dm) fetch(k0 + kBK);
             else if (jt + gridDim.y < ntx) { aim(jt + gridDim.y); fetch(0); }       // the next tile's first step
             // One 16-byte LDS read hands a lane the operands of four matrix instructions: the lane of row fi and half fk takes
             // k = 8 j + 4 fk + e for e = 0..3, so instruction (j, e) multiplies k = 8 j + e (lower half of the wave) and
@@ -217,6 +231,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
 #pragma unroll
                     for (int t = 0; t < 2; t++) { a[t] = an[t]; b[t] = bn[t]; }
                 }
+            }
+            if (last_step) {
+                // k = 32 .. 35 of the step: the lane of half fk takes k = 32 + 2 fk + e for e = 0, 1, so instruction e multiplies
+                // k = 32 + e (lower half of the wave) and k = 34 + e (upper half)
+                float2 a2[2], b2[2];
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    a2[t] = *reinterpret_cast<const float2*>(&As[(wr * 64 + t * 32 + fi) * kLd + kBK + 2 * fk]);
+                    b2[t] = *reinterpret_cast<const float2*>(&Bs[(wc * 64 + t * 32 + fi) * kLd + kBK + 2 * fk]);
+                }
+#pragma unroll
+                for (int ta = 0; ta < 2; ta++)
+#pragma unroll
+                    for (int tb = 0; tb < 2; tb++) {
+                        acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[ta].x, b2[tb].x, acc[ta][tb], 0, 0, 0);
+                        acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[ta].y, b2[tb].y, acc[ta][tb], 0, 0, 0);
+                    }
             }
             __syncthreads();
         }
@@ -388,7 +419,9 @@ float bruteforce_knn(const float* d_base, uint32_t n, const float* d_queries, ui
     hipStream_t stream = (hipStream_t)stream_v;
     const uint32_t kp = k + 8;                        // kept entries: a margin beyond k for the final re-scoring
     const bool vec = (d & 3u) == 0 && ((uintptr_t)d_base & 15u) == 0 && ((uintptr_t)d_queries & 15u) == 0;
-    const bool tail = (d % (uint32_t)kBK) != 0;      // rows end inside a k step
+    // four dims past the last full k step ride along with it (HNSW_AMD_BF_NO_FOLD: measure without)
+    const bool fold = vec && d >= 36u && (d % (uint32_t)kBK) == 4u && getenv("HNSW_AMD_BF_NO_FOLD") == nullptr;
+    const bool tail = !fold && (d % (uint32_t)kBK) != 0;                  // rows end inside a k step
     constexpr uint32_t kCap = 1024;                   // candidate list per query and chunk
     // plain path: distance matrix of at most about 1 GiB at a time
     const uint32_t cw = (uint32_t)std::min<uint64_t>(n, std::max<uint64_t>(kBN, ((1ull << 28) / nq) / kBN * kBN));
@@ -443,7 +476,7 @@ float bruteforce_knn(const float* d_base, uint32_t n, const float* d_queries, ui
                 const uint32_t valid = std::min(cw, hi - x0);
                 timed([&] {
                     const uint32_t ntx = (valid + kBN - 1) / kBN;
-                    hipLaunchKernelGGL((tail ? (vec ? dist_tile_kernel<false, true, true> : dist_tile_kernel<false, false, true>) : (vec ? dist_tile_kernel<false, true, false> : dist_tile_kernel<false, false, false>)), dim3((nq + kBM - 1) / kBM, workers_for(ntx)), dim3(256), 0, stream,
+                    hipLaunchKernelGGL((fold ? dist_tile_kernel<false, true, false, true> : tail ? (vec ? dist_tile_kernel<false, true, true> : dist_tile_kernel<false, false, true>) : (vec ? dist_tile_kernel<false, true, false> : dist_tile_kernel<false, false, false>)), dim3((nq + kBM - 1) / kBM, workers_for(ntx)), dim3(256), 0, stream,
                                        d_queries, d_base, qn, xn, nq, n, d, x0, cw, ntx, D, EmitArgs{});
                 });
                 hipLaunchKernelGGL(select_topk_kernel<false>, dim3(nq), dim3(64), pool_bytes, stream, D, cw, x0, id_offset, valid, kp, best_d,
@@ -464,7 +497,7 @@ float bruteforce_knn(const float* d_base, uint32_t n, const float* d_queries, ui
             const EmitArgs em{best_d, kp, cand, cnt, kCap, id_offset};
             timed([&] {
                 const uint32_t ntx = (width + kBN - 1) / kBN;
-                hipLaunchKernelGGL((tail ? (vec ? dist_tile_kernel<true, true, true> : dist_tile_kernel<true, false, true>) : (vec ? dist_tile_kernel<true, true, false> : dist_tile_kernel<true, false, false>)), dim3((nq + kBM - 1) / kBM, workers_for(ntx)), dim3(256), 0, stream,
+                hipLaunchKernelGGL((fold ? dist_tile_kernel<true, true, false, true> : tail ? (vec ? dist_tile_kernel<true, true, true> : dist_tile_kernel<true, false, true>) : (vec ? dist_tile_kernel<true, true, false> : dist_tile_kernel<true, false, false>)), dim3((nq + kBM - 1) / kBM, workers_for(ntx)), dim3(256), 0, stream,
                                    d_queries, d_base, qn, xn, nq, n, d, seen, width, ntx, (float*)nullptr, em);
             });
             hipLaunchKernelGGL(select_topk_kernel<true>, dim3(nq), dim3(64), pool_bytes, stream, (const float*)nullptr, 0u, 0u, id_offset, 0u, kp,

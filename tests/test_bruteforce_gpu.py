@@ -10,7 +10,9 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("kind,n,nq,d,k", [("sift", 5000, 70, 128, 10), ("sift", 40000, 300, 128, 100), ("glove", 7000, 33, 100, 11),
                                             ("fmnist", 3000, 20, 784, 10), ("sift", 130, 5, 19, 128),
-                                            ("deep", 70001, 200, 96, 10), ("glove", 50000, 130, 100, 10), ("sift", 20000, 129, 30, 5)])
+                                            ("deep", 70001, 200, 96, 10), ("glove", 50000, 130, 100, 10), ("sift", 20000, 129, 30, 5),
+                                            # d % 32 == 4: the last four dims ride along with the last full k step
+                                            ("sift", 9000, 50, 100, 10), ("sift", 3000, 17, 36, 7), ("sift", 4000, 20, 132, 10)])
 @pytest.mark.parametrize("tiles_per_worker", [None, "3"])
 def test_bruteforce_matches_cpu_scan(kind, n, nq, d, k, tiles_per_worker, monkeypatch):
     import torch
