@@ -77,7 +77,17 @@ while time.time() < t_end:
             # once more: the second batch is sized from what the first one needed (other forms of the visited set)
             ids2, ds2, cnt2 = h.search_batch(q, ef, out_k=out_k, flags=flags)
             assert np.array_equal(ids, ids2) and np.array_equal(ds.view(np.uint32), ds2.view(np.uint32)) and np.array_equal(cnt, cnt2), "second call differs"
-        idx = oracle.OracleIndex(h.export_flat(), base)
+        g = h.export_flat()
+        if build != "seq":
+            # a concurrent or GPU build: the lists are well formed whatever the interleaving was
+            adj = g.adj0.reshape(n, g.deg0)
+            live = np.arange(g.deg0)[None, :] < g.cnt0[:, None]
+            assert (adj[live] < n).all() and (adj[~live] == 0xFFFFFFFF).all(), "layer 0: entries out of range or padding broken"
+            assert g.cnt0.min() >= 1, "a vector without links"
+            assert not (adj == np.arange(n, dtype=np.uint32)[:, None]).any(), "self loop"
+            srt = np.sort(np.where(live, adj.astype(np.int64), -1 - np.arange(g.deg0)[None, :]), axis=1)
+            assert (srt[:, 1:] != srt[:, :-1]).all(), "duplicate neighbour"
+        idx = oracle.OracleIndex(g, base)
         oi, od, oc, ost = idx.search(q, ef, out_k=out_k, dist_mode=oracle.DIST_IP if ip else (oracle.DIST_SCALAR if dist == "scalar" else oracle.DIST_SSE),
                                      key_mode=oracle.KEYS_FLOAT if keys_float else oracle.KEYS_INT32, threads=8, stats=True)
         assert np.array_equal(cnt, oc), "counts differ"
