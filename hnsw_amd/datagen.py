@@ -109,12 +109,15 @@ KINDS = {
 
 def make(kind: str, n: int, seed: int = 1, stream: int = 0, *, row0: int = 0, d: int | None = None, threads: int = 1) -> np.ndarray:
     """Rows [row0, row0+n) of the synthetic set `kind` as float32 (n x d).  threads > 1: slices of the rows are generated
-    side by side (every row depends on its own index only, so the result is the same)."""
+    side by side (every row depends on its own index only, so the result is the same); large sets are generated in slices
+    in any case, which bounds the temporaries."""
     d = KINDS[kind] if d is None else d
-    if threads > 1 and n >= (1 << 18):
+    if n >= (1 << 18) and (threads > 1 or n > (1 << 21)):
+        # (large sets in slices even on one thread: the float64 temporaries of a slice instead of those of the whole set)
         from concurrent.futures import ThreadPoolExecutor
+        threads = max(1, threads)
         out = np.empty((n, d), dtype=np.float32)
-        step = -(-n // (4 * threads))
+        step = min(-(-n // (4 * threads)), 1 << 20)
         step = -(-step // (1 << 16)) * (1 << 16)
 
         def part(lo: int) -> None:
