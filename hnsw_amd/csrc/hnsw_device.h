@@ -180,6 +180,7 @@ private:
     SearchCall calls_[kMaxCallsInFlight];
     SearchCall noalloc_call_;          // the entry point that allocates nothing: lists in the library's static device array
     void* bufs_[8] = {};
+    size_t up_lists_cap_ = 0;          // upper-layer slots the two list tables (bufs_[4], bufs_[5]) have room for
 };
 
 // Layer 0 of a GPU-assisted build that is selected and linked on the device (hnsw_build.hip): the edge distances next

@@ -700,7 +700,7 @@ void HostIndex::insert_batch(const float* rows, uint32_t n, int threads, Candida
 // ---------------------------------------------------------------------------------------
 // Flat export / import
 // ---------------------------------------------------------------------------------------
-void HostIndex::export_flat(FlatGraph& g, bool with_layer0) const
+void HostIndex::export_flat(FlatGraph& g, bool with_layer0, bool with_upper_lists) const
 {
     const uint32_t nl = (uint32_t)layers_.size();
     g = FlatGraph();
@@ -715,15 +715,20 @@ void HostIndex::export_flat(FlatGraph& g, bool with_layer0) const
     g.up_off.assign(nl + 1, 0);
     for (uint32_t l = 1; l < nl; l++) g.up_off[l + 1] = g.up_off[l] + layers_[l].count;
     const uint32_t U = g.up_off[nl];
-    g.up_order.resize(U); g.up_down.resize(U); g.up_cnt.resize(U);
-    g.up_adj_slot.assign((size_t)U * g.degu, kPad); g.up_adj_order.assign((size_t)U * g.degu, kPad);
+    g.up_order.resize(U); g.up_down.resize(U);
+    if (with_upper_lists) {
+        g.up_cnt.resize(U);
+        g.up_adj_slot.assign((size_t)U * g.degu, kPad); g.up_adj_order.assign((size_t)U * g.degu, kPad);
+    }
     g.ep_slot.resize(nl); g.ep_order.resize(nl);
     for (uint32_t l = 0; l < nl; l++) { g.ep_slot[l] = layers_[l].ep_slot; g.ep_order[l] = layers_[l].ep_order; }
     for (uint32_t l = 1; l < nl; l++) {
         const LayerStore& L = layers_[l];
         const uint32_t off = g.up_off[l];
         for (uint32_t s = 0; s < L.count; s++) {
-            g.up_order[off + s] = L.order[s]; g.up_down[off + s] = L.down[s]; g.up_cnt[off + s] = L.cnt[s];
+            g.up_order[off + s] = L.order[s]; g.up_down[off + s] = L.down[s];
+            if (!with_upper_lists) continue;
+            g.up_cnt[off + s] = L.cnt[s];
             for (uint32_t j = 0; j < L.cnt[s]; j++) {
                 g.up_adj_slot[(size_t)(off + s) * g.degu + j] = L.nb_slot[(size_t)s * L.deg + j];
                 g.up_adj_order[(size_t)(off + s) * g.degu + j] = L.nb_order[(size_t)s * L.deg + j];

@@ -105,7 +105,9 @@ public:
     void save_graph(const char* filename) const;                   // reference file format
     void load_graph(const char* filename);
     void import_flat(const FlatGraph& g, const float* vectors);
-    void export_flat(FlatGraph& g, bool with_layer0 = true) const;     // (without: upper layers and entry points only)
+    // (without layer 0: upper layers and entry points only; without the upper lists: not even up_adj_* / up_cnt — a caller
+    // that reads the lists from layers_[l] itself)
+    void export_flat(FlatGraph& g, bool with_layer0 = true, bool with_upper_lists = true) const;
     uint32_t size() const { return (uint32_t)(actual_node_count_ + 1); }
     const float* row(uint32_t node_order) const { return vector_data_.data() + (size_t)node_order * vector_size_; }
 

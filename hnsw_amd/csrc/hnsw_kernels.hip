@@ -1776,6 +1776,7 @@ void DeviceIndex::release()
     noalloc_call_.d_spill = nullptr;          // (borrowed, never owned)
     drop(noalloc_call_);
     if (device >= 0 && device < kMaxDevices) g_noalloc_headers_zero[device] = false;      // (be sure rather than remember)
+    up_lists_cap_ = 0;
     version = ~0ull; rows_epoch = 0;
 }
 
@@ -1856,6 +1857,7 @@ void DeviceIndex::upload(const HostIndex& h, int dev)
     g.up_down = to_device(fg.up_down, bufs_[3]);
     g.up_adj_slot = to_device(fg.up_adj_slot, bufs_[4]);
     g.up_adj_order = to_device(fg.up_adj_order, bufs_[5]);
+    up_lists_cap_ = fg.up_off[fg.nlayers];
     HIP_CHECK(hipDeviceSynchronize());
     // set-up for the search calls: the pinned word the overflow count is read into, and this GPU's address of the
     // static scratch array (so that a search call itself never has to allocate or look anything up)
@@ -1877,8 +1879,10 @@ void DeviceIndex::refresh_graph(const HostIndex& h, bool with_layer0, FlatGraph*
     if (device < 0 || !g.vectors) throw std::logic_error("refresh_graph: index not on a device");
     if (calls_in_flight()) throw std::logic_error("the index was changed while a search call on it was in flight: finish the call first");
     HIP_CHECK(hipSetDevice(device));
+    // (the upper layers' lists are read from the host's per-layer arrays directly, which have the device's layout:
+    // [slot][degu], 0xFFFFFFFF behind the live entries)
     FlatGraph fg;
-    h.export_flat(fg, false);
+    h.export_flat(fg, false, false);
     if (fg.n != g.n || fg.d != g.d || fg.deg0 != g.deg0 || fg.degu != g.degu || fg.nlayers == 0)
         throw std::logic_error("refresh_graph: the index changed shape");
     if (with_layer0) {
@@ -1886,13 +1890,33 @@ void DeviceIndex::refresh_graph(const HostIndex& h, bool with_layer0, FlatGraph*
         if (lists0.size() < (size_t)g.n * g.deg0) throw std::logic_error("refresh_graph: layer 0 is shorter than the index");
         HIP_CHECK(hipMemcpy(const_cast<uint32_t*>(g.adj0), lists0.data(), (size_t)g.n * g.deg0 * 4, hipMemcpyHostToDevice));
     }
-    for (int b = 2; b <= 5; b++) { if (bufs_[b]) HIP_CHECK(hipFree(bufs_[b])); bufs_[b] = nullptr; }
+    for (int b = 2; b <= 3; b++) { if (bufs_[b]) HIP_CHECK(hipFree(bufs_[b])); bufs_[b] = nullptr; }
     g.nlayers = fg.nlayers;
     g.top_ep_slot = fg.ep_slot[fg.nlayers - 1]; g.top_ep_order = fg.ep_order[fg.nlayers - 1];
     g.up_off = to_device(fg.up_off, bufs_[2]);
     g.up_down = to_device(fg.up_down, bufs_[3]);
-    g.up_adj_slot = to_device(fg.up_adj_slot, bufs_[4]);
-    g.up_adj_order = to_device(fg.up_adj_order, bufs_[5]);
+    // the two list tables keep their buffers from refresh to refresh (grown with headroom when the layers outgrow them)
+    const size_t U = fg.up_off[fg.nlayers];
+    if (U > up_lists_cap_ || !bufs_[4] || !bufs_[5]) {
+        for (int b = 4; b <= 5; b++) { if (bufs_[b]) HIP_CHECK(hipFree(bufs_[b])); bufs_[b] = nullptr; }
+        up_lists_cap_ = 0;
+        const size_t cap = U + U / 8 + 1024;
+        HIP_CHECK(hipMalloc(&bufs_[4], cap * g.degu * 4));
+        HIP_CHECK(hipMalloc(&bufs_[5], cap * g.degu * 4));
+        up_lists_cap_ = cap;
+    }
+    uint32_t* d_slot = static_cast<uint32_t*>(bufs_[4]);
+    uint32_t* d_order = static_cast<uint32_t*>(bufs_[5]);
+    for (uint32_t l = 1; l < fg.nlayers; l++) {
+        const LayerStore& L = h.layers_[l];
+        const size_t words = (size_t)L.count * g.degu;
+        if (L.deg != g.degu || L.nb_slot.size() < words || L.nb_order.size() < words) throw std::logic_error("refresh_graph: an upper layer's lists do not have the index's shape");
+        if (words == 0) continue;
+        HIP_CHECK(hipMemcpy(d_slot + (size_t)fg.up_off[l] * g.degu, L.nb_slot.data(), words * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(d_order + (size_t)fg.up_off[l] * g.degu, L.nb_order.data(), words * 4, hipMemcpyHostToDevice));
+    }
+    g.up_adj_slot = d_slot;
+    g.up_adj_order = d_order;
     HIP_CHECK(hipDeviceSynchronize());
     if (with_layer0) version = h.version_;
     if (exported) *exported = std::move(fg);
