@@ -133,6 +133,7 @@ int hnsw_amd_insert_batch_assisted(hnsw_amd_index* h, const float* rows, uint32_
 /* The same loop with all of layer 0 on the GPU: after the search of a sub-batch (as above), selectNeighbors for the new
  * vectors (src/hnsw.cpp:263, 1078-1126), their own lists, the links back from every selected neighbour and the
  * re-selection of a neighbour's list that is full (src/hnsw.cpp:266-312) run as kernels on the device's copy of layer 0;
+ * a sub-batch here is a sixty-fourth of the nodes linked so far (65536 at most);
  * the links of a sub-batch are sorted by neighbour and every neighbour's list is updated by one wavefront, in the order
  * of the new vectors' ids, so the graph does not depend on timing.  The host threads only insert the one vector in
  * sixteen that lives in upper layers into those layers; layer 0 is copied back into the host's arrays when the call
