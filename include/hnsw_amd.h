@@ -136,7 +136,7 @@ int hnsw_amd_insert_batch_assisted(hnsw_amd_index* h, const float* rows, uint32_
  * a sub-batch here is a sixty-fourth of the nodes linked so far (65536 at most);
  * the links of a sub-batch are sorted by neighbour and every neighbour's list is updated by one wavefront, in the order
  * of the new vectors' ids, so the graph does not depend on timing.  The host threads only insert the one vector in
- * sixteen that lives in upper layers into those layers; layer 0 is copied back into the host's arrays when the call
+ * sixteen that lives in upper layers into those layers (its layer-1 candidate list comes from a device search on that layer too); layer 0 is copied back into the host's arrays when the call
  * ends (and around a vector that opens a new top layer, which is inserted on the host).  Distances between two stored
  * vectors are summed in another order than insert() does, so comparisons that are near-ties may fall differently: a
  * valid HNSW graph of the same rule, neither the reference's exact adjacency nor the assisted build's.  For M <= Mmax0
