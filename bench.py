@@ -248,7 +248,8 @@ def main():
     sweep = []
     ef_pick = args.ef
     # shards see fewer points each, so a sharded run may reach the target below the reference's first value (20)
-    sweep_values = harness.REFERENCE_EF_SWEEP if parts == 1 else [10, 12, 14, 16, 18] + harness.REFERENCE_EF_SWEEP
+    # (... and between its first values in steps of two: a shard's search time grows with ef, the merged recall with it)
+    sweep_values = harness.REFERENCE_EF_SWEEP if parts == 1 else sorted(set(list(range(10, 40, 2)) + list(harness.REFERENCE_EF_SWEEP)))
     for ef in ([args.ef] if args.ef else sweep_values):
         step(ef, k)
         torch.cuda.synchronize()
