@@ -533,7 +533,8 @@ struct QRegs {
 __host__ __device__ constexpr bool query_overlaid(int NL, int ROWS, bool SCALAR, int NBUF) { return NL == 6 && ROWS == 0 && !SCALAR && NBUF == 2; }
 // which of the three a kernel's ROWS parameter means (ROWS: 0 float rows, 1 exact byte rows, 2 quantised byte rows,
 // 3 exact byte rows through integer dot products)
-__host__ __device__ constexpr int row_kind(int ROWS) { return ROWS == 0 ? 0 : (ROWS == 3 ? 2 : 1); }
+__host__ __device__ constexpr int row_kind(int ROWS) { return ROWS == 0 ? 0 : (ROWS >= 3 ? 2 : 1); }
+__host__ __device__ constexpr bool rows_quantised(int ROWS) { return ROWS == 2 || ROWS == 4; }
 template <int NL, int RK>
 __device__ __forceinline__ void qregs_load(QRegs<NL, RK>& qr, const float* qs, int lane)
 {
@@ -916,11 +917,11 @@ __device__ __forceinline__ void rows_distance(const DeviceGraph& g, const DistCt
     typedef RowMap<SCALAR> RM;
     if constexpr (ROWS != 0) {
         static_assert(!SCALAR, "byte rows are read in SSE order only");
-        const uint8_t* const table = ROWS == 2 ? g.vectors_q8 : g.vectors_u8;
+        const uint8_t* const table = rows_quantised(ROWS) ? g.vectors_q8 : g.vectors_u8;
         const uint8_t* row[2];
 #pragma unroll
         for (int s = 0; s < 2; s++) row[s] = table + (size_t)id[s] * g.row_stride_u8 + 32u * (lane & 3);
-        if constexpr (ROWS == 3) batch_distance_dot4<NL>(c, row, act, out, lane, qr);
+        if constexpr (ROWS >= 3) batch_distance_dot4<NL>(c, row, act, out, lane, qr);
         else batch_distance_u8<NL>(c, row, act, out, lane, qr);
     } else {
         if constexpr (SCALAR) {
@@ -1065,6 +1066,7 @@ __device__ __forceinline__ uint32_t w_set_replace_max(uint32_t (&wd)[WR], uint32
 //         exactly the worst distance is dropped.
 // ROWS = 0: rows are read from the float table.
 // ROWS = 1: from the exact byte table (DeviceGraph::vectors_u8): same arithmetic, same results.
+// ROWS = 4: the quantised byte table through integer dot products (the query rounded to the table's grid), results re-scored like ROWS = 2.
 // ROWS = 2: from the quantised byte table (vectors_q8) with the query mapped to the same grid, so the
 //           search runs on approximate distances; its ef results are then re-scored with the exact
 //           float distance and sorted by it.
@@ -1168,7 +1170,7 @@ __global__ __launch_bounds__(NBUF == 2 ? 64 : 128) __attribute__((amdgpu_waves_p
 
     // query into LDS in stored form (zero padded), visited set empty
     QRegs<NL, row_kind(ROWS)> qr;
-    if constexpr (ROWS == 3) {
+    if constexpr (ROWS >= 3) {
         // as packed bytes (a.qpad counts dwords of four); a query with an element that is not an integer in 0..255 cannot
         // take the integer arithmetic: it is handed back like a query that outgrew its scratch (the re-run uses floats)
         const float* q = a.queries + (size_t)qi * a.g.d;
@@ -1177,9 +1179,11 @@ __global__ __launch_bounds__(NBUF == 2 ? 64 : 128) __attribute__((amdgpu_waves_p
         bool inexact = false;
         uint32_t sq = 0;
         for (uint32_t i = lane; i < 4u * a.qpad; i += 64) {
-            const float v = i < d_used ? q[i] : 0.0f;
+            float v = i < d_used ? q[i] : 0.0f;
+            if (ROWS == 4 && i < d_used) v = __builtin_rintf((v - a.g.q8_lo) * a.g.q8_inv_step);      // the query on the table's grid, rounded
+            if (ROWS == 4) v = v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v);
             const uint32_t b = (uint32_t)(v >= 0.0f && v <= 255.0f ? (int)v : 0);
-            inexact = inexact || (float)b != v;
+            inexact = inexact || (ROWS == 3 && (float)b != v);
             sq += b * b;
             qb[stored_pos_u8(i)] = (uint8_t)b;
         }
@@ -1515,7 +1519,7 @@ __global__ __launch_bounds__(NBUF == 2 ? 64 : 128) __attribute__((amdgpu_waves_p
     // Only entries that can rank below out_k take part in the sort: those not farther than the out_k-th smallest
     // distance `dk`.  (The quantised-row mode re-scores everything first, so it sorts everything.)
     uint32_t nsort = nW;
-    if constexpr (WR >= 2 && ROWS != 2) {
+    if constexpr (WR >= 2 && !rows_quantised(ROWS)) {
         // W is an unordered set in registers: find dk by taking minima (counting ties) until out_k entries are
         // covered, then write the entries up to dk to LDS back to back
         uint32_t dk = 0xFFFFFFFFu;
@@ -1554,7 +1558,7 @@ __global__ __launch_bounds__(NBUF == 2 ? 64 : 128) __attribute__((amdgpu_waves_p
             if ((uint32_t)(w * 64 + lane) < nW) W[w * 64 + lane] = make_uint2(wd[w], wi[w]);
         LDS_SYNC();
     }
-    if constexpr (ROWS == 2) {
+    if constexpr (rows_quantised(ROWS)) {
         // the search ran on the quantised table: replace every result's distance by the exact one
         // (float rows, the reference's SSE order) before sorting
         const float* q = a.queries + (size_t)qi * a.g.d;
@@ -1576,7 +1580,7 @@ __global__ __launch_bounds__(NBUF == 2 ? 64 : 128) __attribute__((amdgpu_waves_p
         LDS_SYNC();
     }
     // The one-register form wrote W in ascending order of distance, so the entries up to dk are the first ones.
-    if (WR == 1 && ROWS != 2 && a.out_k < nW) {
+    if (WR == 1 && !rows_quantised(ROWS) && a.out_k < nW) {
         const uint32_t dk = w_entry_dist<(WR > 0 ? WR : 1)>(wd, a.out_k - 1);
         nsort = 0;
 #pragma unroll
@@ -2038,7 +2042,7 @@ typedef void (*SearchKernel)(SearchArgs);
 template <bool SCALAR, int ROWS, bool BUCKET, int NBUF, bool IP = false, int NL = 0>
 static SearchKernel pick_wr(int wr, int wps = 4, bool packc = false)
 {
-    if constexpr (ROWS == 3) { if (wr == 1 && wps == 6) return hnsw_search_kernel<SCALAR, 1, ROWS, BUCKET, NBUF, IP, NL, 6>; }
+    if constexpr (ROWS >= 3) { if (wr == 1 && wps == 6) return hnsw_search_kernel<SCALAR, 1, ROWS, BUCKET, NBUF, IP, NL, 6>; }
     if constexpr (ROWS == 0 && !IP && NBUF == 2) {
         if (packc && wr == 1) return hnsw_search_kernel<SCALAR, 1, 0, BUCKET, 2, false, NL, 4, true>;
         if (packc && wr == 2) return hnsw_search_kernel<SCALAR, 2, 0, BUCKET, 2, false, NL, 4, true>;
@@ -2061,6 +2065,8 @@ static SearchKernel pick_rows(bool scalar, int wr, int rows, bool ip, int nl, in
     if (scalar) return pick_wr<true, 0, BUCKET, 2>(wr, 4, packc);
     if (rows == 3 && nl == 8) return pick_wr<false, 3, BUCKET, 2, false, 8>(wr, wps);
     if (rows == 3) return pick_wr<false, 3, BUCKET, 2>(wr, wps);
+    if (rows == 4 && nl == 8) return pick_wr<false, 4, BUCKET, 2, false, 8>(wr, wps);
+    if (rows == 4) return pick_wr<false, 4, BUCKET, 2>(wr, wps);
     if (rows == 1 && nl == 8) return pick_wr<false, 1, BUCKET, 2, false, 8>(wr);
     if (rows == 2 && nl == 8) return pick_wr<false, 2, BUCKET, 2, false, 8>(wr);
     if (rows == 1) return pick_wr<false, 1, BUCKET, 2>(wr);
@@ -2345,11 +2351,14 @@ void DeviceIndex::launch_tier(SearchCall& c)
     // and re-run with the float arithmetic; an index whose queries mostly are not stops trying.
     const bool dot4 = u8 && tier == 0 && !tune.no_dot4 && !dot4_off && (uint64_t)(g.d & ~15u) * 65025ull < (1ull << 24);
     c.dot4 = dot4;
-    a.qpad = dot4 ? ((g.d + 127u) & ~127u) / 4u : ((u8 || q8) ? ((g.d + 127u) & ~127u) : ((g.d + 63u) & ~63u));
+    // ... and the quantised rows likewise (an approximation either way: the query is rounded to the table's grid, the
+    // kernel re-scores its results with the float rows, for which the query's LDS region must hold the float query)
+    const bool dot4q = q8 && tier == 0 && !tune.no_dot4 && (uint64_t)(g.d & ~15u) * 65025ull < (1ull << 24);
+    a.qpad = dot4 ? ((g.d + 127u) & ~127u) / 4u : (dot4q ? std::max(((g.d + 127u) & ~127u) / 4u, (g.d + 63u) & ~63u) : ((u8 || q8) ? ((g.d + 127u) & ~127u) : ((g.d + 63u) & ~63u)));
     const uint32_t want_visit = c.want_visit0 << tier;
     const bool std_heap = (flags & HNSW_AMD_W_STD_HEAP) != 0 || ef > 256;
     const int wr = std_heap ? 0 : (ef <= 64 ? 1 : (ef <= 128 ? 2 : 4));
-    const int rows_kind = dot4 ? 3 : (u8 ? 1 : (q8 ? 2 : 0));
+    const int rows_kind = dot4 ? 3 : (dot4q ? 4 : (u8 ? 1 : (q8 ? 2 : 0)));
     const bool wide_small = g.d > 256 && (uint64_t)a.nq_launch <= 4ull * (uint64_t)num_cus && !tune.no_deep_rows;   // (the two-wavefront form)
     // Candidate-heap entries of four bytes (key in the top byte, node_order below) where that is provably enough: fewer
     // than 2^24 rows, int32 keys, and no row so long that a query of ordinary length could be 250 away from it (the
@@ -2367,7 +2376,7 @@ void DeviceIndex::launch_tier(SearchCall& c)
     const SearchArgs a_in = a;
     // Wavefronts per SIMD of the kernel: 6 (24 queries per CU) where such a kernel exists (integer dot products, ef <= 64)
     // and the scratch of a query then fits a 24th of the LDS, else 4 (16 per CU).
-    int wps = (rows_kind == 3 && wr == 1 && (uint64_t)a.nq_launch >= 16ull * (uint64_t)num_cus && tune.lds_budget < 0) ? 6 : 4;
+    int wps = (rows_kind >= 3 && wr == 1 && (uint64_t)a.nq_launch >= 16ull * (uint64_t)num_cus && tune.lds_budget < 0) ? 6 : 4;
     for (;; wps = 4) {
         a = a_in;
         a.spill_pool = nullptr; a.spill_tables = 0; a.spill_slots = 0; a.vis_regions = 0; a.vis_magic = 0;

@@ -62,10 +62,13 @@ def test_byte_rows_refused_for_other_data():
 
 
 @pytest.mark.parametrize("kind,n,ef", [("glove", 40000, 60), ("deep", 40000, 60), ("sift", 40000, 50), ("gist", 6000, 64)])
-def test_quantised_rows_search_then_exact_rescoring(kind, n, ef):
+def test_quantised_rows_search_then_exact_rescoring(kind, n, ef, monkeypatch):
     """HNSW_AMD_ROWS_Q8 is an approximation of the reference's search (never used for parity): what is
     checked is that the reported distances are the exact float distances of the reported ids, in order,
-    and that recall against exact brute force stays close to the float-row search's."""
+    and that recall against exact brute force stays close to the float-row search's — through the integer dot
+    products (rows of up to 271 dims: the query rounded to the table's grid) and through the float arithmetic
+    (HNSW_AMD_NO_DOT4, and the 960-dim set whatever the switch says), under both key modes, with W in registers
+    (one, two, four per lane) and as the heap in LDS."""
     from oracle import oracle
     from tests.helpers import recall_at_k
     nq, k = 300, 10
@@ -76,15 +79,26 @@ def test_quantised_rows_search_then_exact_rescoring(kind, n, ef):
     h = HNSW(16, 16, 100)
     h.init(d, n)
     h.insert_batch(base, threads=16)
-    ids_f, dist_f, _ = h.search_batch(q, ef, flags=capi.DIST_SSE | capi.KEYS_FLOAT)
-    ids_q, dist_q, cnt_q = h.search_batch(q, ef, flags=capi.DIST_SSE | capi.KEYS_FLOAT | capi.ROWS_Q8)
-    assert (cnt_q == ef).all() and (ids_q < n).all()
-    assert (np.diff(dist_q, axis=1) >= 0).all()
-    exact = ((q[:, None, :used].astype(np.float64) - base[ids_q][:, :, :used].astype(np.float64)) ** 2).sum(-1)
-    assert np.allclose(dist_q, exact, rtol=1e-5, atol=1e-6)
     gt = oracle.bruteforce(base[:, :used], q[:, :used], k, threads=8)
-    r_f, r_q = recall_at_k(ids_f[:, :k], gt, k), recall_at_k(ids_q[:, :k], gt, k)
-    assert r_q >= r_f - 0.03, (r_f, r_q)
+    for keys in (capi.KEYS_FLOAT, capi.KEYS_INT32):
+        for e, extra in ((ef, 0), (150, 0), (40, capi.W_STD_HEAP), (300, 0)):
+            ids_f, dist_f, _ = h.search_batch(q, e, flags=capi.DIST_SSE | capi.KEYS_FLOAT | extra)
+            r_f = recall_at_k(ids_f[:, :k], gt, k)
+            for no_dot4 in (False, True):
+                if no_dot4:
+                    monkeypatch.setenv("HNSW_AMD_NO_DOT4", "1")
+                else:
+                    monkeypatch.delenv("HNSW_AMD_NO_DOT4", raising=False)
+                h.reload_env()
+                ids_q, dist_q, cnt_q = h.search_batch(q, e, flags=capi.DIST_SSE | keys | capi.ROWS_Q8 | extra)
+                assert (cnt_q == e).all() and (ids_q < n).all()
+                assert (np.diff(dist_q, axis=1) >= 0).all()
+                exact = ((q[:, None, :used].astype(np.float64) - base[ids_q][:, :, :used].astype(np.float64)) ** 2).sum(-1)
+                assert np.allclose(dist_q, exact, rtol=1e-5, atol=1e-6)
+                r_q = recall_at_k(ids_q[:, :k], gt, k)
+                assert r_q >= r_f - 0.03, (kind, keys, e, extra, no_dot4, r_f, r_q)
+    monkeypatch.delenv("HNSW_AMD_NO_DOT4", raising=False)
+    h.reload_env()
 
 
 @pytest.mark.parametrize("d,extra", [(128, 0), (128, capi.W_STD_HEAP), (200, 0), (48, capi.KEYS_FLOAT), (272, 0)])
