@@ -85,6 +85,25 @@ int main(int argc, char** argv)
     EXPECT(other.W_.size() == hnsw.W_.size());
     for (size_t i = 0; i < hnsw.W_.size(); i++) EXPECT(other.W_[i].distance == hnsw.W_[i].distance);
 
+    // the batched calls of the class: an index whose layer 0 is built on the GPU, under the reference's plain (all-dims)
+    // distance, searched as one batch: every stored row finds itself first
+    {
+        const uint32_t nb = 6000;
+        std::vector<float> big((size_t)nb * d);
+        for (auto& v : big) { x = x * 1664525u + 1013904223u; v = (float)((x >> 16) % 251); }
+        HNSW built(16, 16, 100);
+        built.init(d, nb);
+        built.setBuildScalarDistance(true);
+        built.search_flags |= HNSW_AMD_DIST_SCALAR;
+        built.insertBatchDevice(big.data(), nb, 4);
+        EXPECT(built.actual_node_count_ == (int)nb - 1);
+        const uint32_t nq = 500, take = 3;
+        std::vector<uint32_t> ids((size_t)nq * take);
+        std::vector<float> dist((size_t)nq * take);
+        built.searchBatch(big.data(), nq, 40, take, ids.data(), dist.data());
+        for (uint32_t i = 0; i < nq; i++) EXPECT(dist[(size_t)i * take] == 0.0f);
+    }
+
     // linearHash as a container (src/hnsw.h:55-125)
     linearHash set(64);
     set.clear();
