@@ -139,3 +139,16 @@ def test_linked_build_with_long_lists_falls_back():
     _check_lists(g, n)
     ids, dist, _ = h.search_batch(base[:100], 30, out_k=1)
     assert (dist[:, 0] == 0).all()
+
+
+def test_linked_build_refuses_a_gpu_that_is_not_there():
+    from hnsw_amd import capi
+    base = datagen.make("sift", 3000, seed=16)
+    h = HNSW(16, 16, 100)
+    h.init(128, 3000)
+    rc = capi.lib().hnsw_amd_insert_batch_linked(h._h, capi.f32(base), 3000, 4, 99)
+    assert rc != 0 and b"no such GPU" in capi.lib().hnsw_amd_last_error()
+    # the index is untouched and still usable
+    h.insert_batch(base, threads=4, gpu="link")
+    ids, dist, _ = h.search_batch(base[:50], 30, out_k=1)
+    assert (dist[:, 0] == 0).all()
