@@ -151,7 +151,11 @@ int hnsw_amd_insert_batch_assisted(hnsw_amd_index* h, const float* rows, uint32_
 // Layer 0 of the build on the device (hnsw_build.hip): the three callbacks of HostIndex::Layer0Linker.
 static uint32_t build_flags(const hnsw_amd_index* h)
 {
-    return (h->host.dist_scalar_ ? HNSW_AMD_DIST_SCALAR : HNSW_AMD_DIST_SSE) | (h->host.build_float_keys_ ? HNSW_AMD_KEYS_FLOAT : HNSW_AMD_KEYS_INT32);
+    uint32_t flags = (h->host.dist_scalar_ ? HNSW_AMD_DIST_SCALAR : HNSW_AMD_DIST_SSE) | (h->host.build_float_keys_ ? HNSW_AMD_KEYS_FLOAT : HNSW_AMD_KEYS_INT32);
+    // integer-valued rows (an exact byte table exists): the construction searches read it — the same distances bit for
+    // bit, so the same graph, from a quarter of the bytes
+    if (!h->host.dist_scalar_ && h->dev.g.vectors_u8 != nullptr) flags |= HNSW_AMD_ROWS_U8;
+    return flags;
 }
 
 static void linked_from_host(void* ctx)
